@@ -1,0 +1,197 @@
+/*
+ * rt_hip.h - C ABI of the MI355X (gfx950) render-loop library, librt_hip.so.
+ *
+ * This is the boundary a host program (the reference's Rust crate through an
+ * `extern "C"` block, the bundled C++ headless driver, or Python through
+ * ctypes) binds to.  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * The reference (ojferro/raytracing) has no FFI of its own.  The seam this
+ * header replaces is the worker call
+ *     calculate_some_pxls(...)            src/raytracer.rs:164-168, 232-271
+ * plus the fan-in that quantises each pixel
+ *     write_colour(...)                   src/raytracer.rs:46-55, 176-185
+ * Every entry point cites the reference code whose role it takes.
+ *
+ * Conventions
+ *   - every function returns RT_OK (0) or a negative RT_E_* code; no panic or
+ *     exception crosses the boundary (the reference `.unwrap()`s instead:
+ *     src/raytracer.rs:126,204,268).  rt_last_error() gives the text.
+ *   - a context belongs to one GPU and is not thread-safe; different contexts
+ *     may be driven from different host threads.
+ *   - all arithmetic is IEEE binary32 without fused contraction, as in the
+ *     reference (src/vector/mod.rs:141-189).
+ *   - image rows: `j` counts from the BOTTOM of the picture (src/raytracer.rs:245,
+ *     256); buffers handed back are in display order, row = height-1-j
+ *     (src/raytracer.rs:265).
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+enum {
+    RT_OK = 0,
+    RT_E_BADARG = -1, /* null pointer, size out of range, malformed scene */
+    RT_E_HIP = -2,    /* a HIP runtime call failed (text in rt_last_error) */
+    RT_E_OOM = -3,    /* host or device allocation failed */
+    RT_E_STATE = -4,  /* call order: tables/scene/camera/frame not set */
+    RT_E_IO = -5      /* file could not be written */
+};
+
+/* Material kinds: Metal / Lambertian / Dielectric, src/geometry/mod.rs:268-346 */
+enum { RT_METAL = 0, RT_LAMBERTIAN = 1, RT_DIELECTRIC = 2 };
+
+/* Sampling schedules.
+ * RT_SAMPLING_DET: every table index is a pure function of (pixel, sample,
+ *   bounce, seed).  The two disc draws of sample n = (j*W+i)*spp+s use table
+ *   entries (2n+1)%64 and (2n+2)%64, which is what the reference's global
+ *   counter (src/denoising/mod.rs:12-18) yields for one worker thread on its
+ *   first frame; primary rays are therefore those of the reference.  The
+ *   unit-sphere counter (src/denoising/mod.rs:37-41) starts at a per-path hash
+ *   and advances once per closest-hit Metal/Lambertian scatter; the Dielectric
+ *   coin (src/geometry/mod.rs:319) is a hash of (path, bounce).
+ * RT_SAMPLING_REF_SEQ_PRIMARY is the same schedule under the name that says
+ *   what it guarantees: reference-identical primary rays. */
+enum { RT_SAMPLING_DET = 0, RT_SAMPLING_REF_SEQ_PRIMARY = 0 };
+
+#define RT_BAND_ROWS 8u      /* rows per band = tile height of one wavefront */
+#define RT_MAX_BOUNCES 16u   /* the reference uses 10 (src/raytracer.rs:132) */
+
+/*
+ * Scene as structure-of-arrays, one group per primitive kind
+ * (HittableList, src/geometry/mod.rs:228-238; Scene::get_scene,
+ * src/scene/mod.rs:15-57).  `*_id[k]` is the position of that primitive in
+ * the reference's insertion-ordered list; the ids of all groups together must
+ * be a permutation of 0..n-1.  List order decides ties and is the id that
+ * rt_read_primary_ids() reports.  All arrays are copied by rt_upload_scene().
+ */
+typedef struct rt_scene {
+    /* Sphere{center, radius}: src/geometry/mod.rs:47-57 (radius may be < 0) */
+    uint32_t n_spheres;
+    const float *sph_cx, *sph_cy, *sph_cz, *sph_r;
+    const uint32_t *sph_mat, *sph_id;
+    /* Plane{normal, point}: src/geometry/mod.rs:97-109 */
+    uint32_t n_planes;
+    const float *pl_nx, *pl_ny, *pl_nz, *pl_px, *pl_py, *pl_pz;
+    const uint32_t *pl_mat, *pl_id;
+    /* Cube{center, w, h, d}: src/geometry/mod.rs:134-155 (corners derived) */
+    uint32_t n_cubes;
+    const float *cb_cx, *cb_cy, *cb_cz, *cb_w, *cb_h, *cb_d;
+    const uint32_t *cb_mat, *cb_id;
+    /* Triangle{v0, v1, v2}: no counterpart in the reference sources (its README
+     * advertises .obj meshes, the code has none).  Semantics defined here:
+     * two-sided Moller-Trumbore with e1 = v1-v0, e2 = v2-v0, plain f32
+     * mul/add, miss when det == 0, u < 0, u > 1, v < 0, u+v > 1,
+     * t < t_min or t_max < t; outward normal unit(cross(e1, e2)), then
+     * set_face_normal and the material scatter like a Sphere. */
+    uint32_t n_tris;
+    const float *tri_v0x, *tri_v0y, *tri_v0z;
+    const float *tri_v1x, *tri_v1y, *tri_v1z;
+    const float *tri_v2x, *tri_v2y, *tri_v2z;
+    const uint32_t *tri_mat, *tri_id;
+    /* materials: kind, albedo, param (Metal: fuzz; Dielectric: index of
+     * refraction; Lambertian: unused) - src/geometry/mod.rs:268-304 */
+    uint32_t n_materials;
+    const int32_t *mat_kind;
+    const float *mat_r, *mat_g, *mat_b, *mat_param;
+} rt_scene;
+
+/* The fields of Camera that get_ray reads, src/camera/mod.rs:9-28,75-79. */
+typedef struct rt_camera {
+    float origin[3];
+    float lower_left_corner[3];
+    float horizontal[3];
+    float vertical[3];
+    float u[3];
+    float v[3];
+    float lens_radius;
+} rt_camera;
+
+/* Arguments of calculate_some_pxls, src/raytracer.rs:232-242, plus the
+ * partitioning the reference does with thread_id/num_threads (:245). */
+typedef struct rt_params {
+    uint32_t width, height;
+    uint32_t spp;           /* samples per pixel of the whole frame */
+    uint32_t sample_begin;  /* this call renders samples [begin, begin+count) */
+    uint32_t sample_count;
+    uint32_t max_bounces;   /* ray_colour depth budget, 10 in the reference */
+    uint32_t gamma;         /* non-zero: sqrt on the sky radiance (:86-90) */
+    float t_min;            /* 0.001 (:75) */
+    uint32_t band_begin;    /* render 8-row bands b with b % band_stride == band_begin */
+    uint32_t band_stride;   /* 1 = whole frame; G = one of G GPUs */
+    uint32_t sampling_mode; /* RT_SAMPLING_DET */
+    uint32_t seed;
+} rt_params;
+
+/* ---- context: takes the place of thread spawn/join, src/raytracer.rs:146-171,203-205 */
+int rt_create(int device, rt_ctx **out);
+void rt_destroy(rt_ctx *ctx);
+const char *rt_last_error(const rt_ctx *ctx); /* ctx may be NULL: last create error */
+
+/* ---- inputs */
+/* tables of src/denoising/mod.rs:55 (64x2), :59 (256x3), :61 (128*128, idx = 128*i+j) */
+int rt_upload_tables(rt_ctx *ctx, const float *disc, const float *sphere, const float *screen);
+int rt_upload_scene(rt_ctx *ctx, const rt_scene *scene);
+int rt_set_camera(rt_ctx *ctx, const rt_camera *cam);
+
+/* ---- frame */
+/* (re)allocate the per-pixel buffers for width x height and zero the sums:
+ * `let mut px_colour = colour::new(0,0,0)`, src/raytracer.rs:249 */
+int rt_begin_frame(rt_ctx *ctx, uint32_t width, uint32_t height);
+/* enqueue the render loop for the bands and samples named in params; adds into
+ * the per-pixel sums (`px_colour += ray_colour(...)`, src/raytracer.rs:262).
+ * Asynchronous on the context's stream. */
+int rt_render(rt_ctx *ctx, const rt_params *params);
+/* enqueue the quantiser write_colour (src/raytracer.rs:46-55) over the whole frame */
+int rt_pack(rt_ctx *ctx);
+int rt_sync(rt_ctx *ctx);
+
+/* ---- outputs (each synchronises the stream; rows in display order) */
+/* PxData.c, src/raytracer.rs:225-230: un-normalised RGB sums, 3 floats per pixel */
+int rt_read_accum(rt_ctx *ctx, float *rgb, size_t n_px);
+/* PxData.num_samples: samples added so far, per pixel */
+int rt_read_sample_counts(rt_ctx *ctx, uint32_t *counts, size_t n_px);
+/* 0x00RRGGBB as written by write_colour; runs rt_pack first */
+int rt_read_packed(rt_ctx *ctx, uint32_t *out, size_t n_px);
+/* list index of the primitive the first segment of sample 0 hit, -1 = sky
+ * (first HittableList::hit call, src/raytracer.rs:75).  No reference output. */
+int rt_read_primary_ids(rt_ctx *ctx, int32_t *ids, size_t n_px);
+/* path segments (= HittableList::hit calls) traced since rt_begin_frame */
+int rt_ray_count(rt_ctx *ctx, uint64_t *segments);
+
+/* ---- device-side access for callers that keep the image on the GPU
+ * (multi-GPU gather).  Pointers stay valid until the next rt_begin_frame or
+ * rt_destroy.  accum: float4 {r,g,b,n} per pixel; packed: uint32 per pixel;
+ * ids: int32 per pixel; all in display order.  stream: the hipStream_t. */
+int rt_device_buffers(rt_ctx *ctx, void **accum, void **packed, void **ids, void **stream);
+/* HIP-event stopwatch on the context's stream; stop synchronises */
+int rt_timer_start(rt_ctx *ctx);
+int rt_timer_stop(rt_ctx *ctx, float *milliseconds);
+
+/* ---- host-side helpers (no GPU needed) */
+/* Camera::new, src/camera/mod.rs:35-73 */
+int rt_camera_new(float v_fov_deg, float aspect_ratio, float aperture, float focus_dist,
+                  const float origin[3], const float look_at[3], const float v_up[3],
+                  rt_camera *out);
+/* Scene::get_camera with the dolly counter made an argument, src/scene/mod.rs:59-76,
+ * and the aperture the reference keeps commented out (:70) */
+int rt_scene_camera(uint32_t counter, float aperture, rt_camera *out);
+/* `(image_width as f32 / aspect_ratio) as usize`, src/raytracer.rs:118-120 */
+uint32_t rt_image_height(uint32_t width, float aspect_ratio);
+/* decimal text -> binary32, round-to-nearest per token like a Rust literal;
+ * returns the number of values found (may exceed cap; only cap are stored) */
+size_t rt_parse_floats(const char *text, size_t len, float *out, size_t cap);
+/* PPM::write_file, src/image/mod.rs:61-67: "P6 {w} {h} 255\n" + RGB bytes */
+int rt_write_ppm(const char *path, const uint32_t *packed, uint32_t width, uint32_t height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

@@ -1,0 +1,778 @@
+/*
+ * rt_oracle.c - CPU restatement of the reference's per-pixel render loop.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and
+ * the cpu_baseline leg of bench.py may load this; the shipped library never
+ * does, and has no CPU fallback.
+ *
+ * What it restates (ojferro/raytracing, Rust, paths relative to the reference
+ * root): src/raytracer.rs:35-55,68-92,232-271; src/geometry/mod.rs:22-39,
+ * 59-94,111-130,157-223,240-258,274-345; src/camera/mod.rs:35-79;
+ * src/denoising/mod.rs:12-23,37-50; src/vector/mod.rs:23-45,91-93,107-189;
+ * src/ray/mod.rs:15-21; src/scene/mod.rs:59-76.  Each function names the lines
+ * it follows.  Scalar binary32 arithmetic, evaluated in the reference's
+ * operand order; build with -ffp-contract=off and without -ffast-math.
+ *
+ * How parity is pinned.  The reference is Rust; no rustc/cargo exists in the
+ * build image or on the GPU box and its crates are not vendored, so the
+ * reference cannot be run, and it holds no tests, golden vectors or fixtures
+ * for this path.  Pinned by reference DATA: the three lookup tables (token-
+ * identical to src/denoising/mod.rs:55,59,61 and the data/ text twins, sha256 in
+ * tests/golden/tables.sha256) and the scene/camera literals.  The arithmetic
+ * is pinned only by hand-derived known-answer tests written from the cited
+ * source lines (tests/test_oracle_kat.py): for those parts PARITY IS UNPINNED
+ * by any reference output.  The Dielectric coin of the reference is an
+ * OS-seeded ChaCha12 `rand::thread_rng()` (rand 0.8.3, src/geometry/mod.rs:319)
+ * and its table counters are racy globals, so even the real binary does not
+ * reproduce itself; mode ORC_MODE_REF_SEQ follows the one-thread ordering of
+ * those counters with a PCG32 coin, mode ORC_MODE_DET is the pure-function
+ * schedule the GPU library implements (rt_hip.h, RT_SAMPLING_DET).
+ *
+ * Triangles have no counterpart in the reference sources; tri_hit() is the
+ * definition given in rt_hip.h.
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/rt_hip.h"
+
+#define ORC_MODE_DET 0
+#define ORC_MODE_REF_SEQ 1
+
+/* ------------------------------------------------------------------ vec3 */
+/* src/vector/mod.rs:12-16 */
+typedef struct { float x, y, z; } vec3;
+
+static inline vec3 v3(float x, float y, float z) { vec3 r = {x, y, z}; return r; }
+/* src/vector/mod.rs:141-149 */
+static inline vec3 v_add(vec3 a, vec3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+/* src/vector/mod.rs:151-159 */
+static inline vec3 v_sub(vec3 a, vec3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+/* src/vector/mod.rs:162-170 */
+static inline vec3 v_mulf(vec3 a, float t) { return v3(a.x * t, a.y * t, a.z * t); }
+/* src/vector/mod.rs:171-179 */
+static inline vec3 v_mulv(vec3 a, vec3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+/* src/vector/mod.rs:181-189 */
+static inline vec3 v_divf(vec3 a, float t) { return v3(a.x / t, a.y / t, a.z / t); }
+/* src/vector/mod.rs:107-115 */
+static inline vec3 v_neg(vec3 a) { return v3(-a.x, -a.y, -a.z); }
+/* src/vector/mod.rs:23-25 */
+static inline float v_len2(vec3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+/* src/vector/mod.rs:26-28 */
+static inline float v_len(vec3 a) { return sqrtf(v_len2(a)); }
+/* src/vector/mod.rs:34-36 */
+static inline float v_dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+/* src/vector/mod.rs:38-42 */
+static inline vec3 v_cross(vec3 a, vec3 b) {
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+/* src/vector/mod.rs:44-46 */
+static inline vec3 v_unit(vec3 a) { return v_divf(a, v_len(a)); }
+/* src/vector/mod.rs:29-32: the test ignores eps and asks for three negative
+ * components */
+static inline int v_is_near_zero(vec3 a) { return a.x < 0.0f && a.y < 0.0f && a.z < 0.0f; }
+/* src/vector/mod.rs:91-93: v - (n*2.0)*dot(v,n) */
+static inline vec3 v_reflect(vec3 v, vec3 n) {
+    return v_sub(v, v_mulf(v_mulf(n, 2.0f), v_dot(v, n)));
+}
+
+/* Rust `f32::min`: the other operand when one is NaN */
+static inline float f_min(float a, float b) {
+    if (a != a) return b;
+    if (b != b) return a;
+    return a < b ? a : b;
+}
+/* Rust `as i32` from f32: truncate, saturate, NaN -> 0 */
+static inline int32_t f_to_i32(float x) {
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return INT32_MAX;
+    if (x <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)x;
+}
+/* Rust `as u8` from f32: truncate, saturate, NaN -> 0 */
+static inline uint32_t f_to_u8(float x) {
+    if (x != x) return 0;
+    if (x >= 255.0f) return 255;
+    if (x <= 0.0f) return 0;
+    return (uint32_t)(int32_t)x;
+}
+
+/* ------------------------------------------------------------------- ray */
+/* src/ray/mod.rs:9-12 */
+typedef struct { vec3 origin, dir; } ray_t;
+/* src/ray/mod.rs:19-21 */
+static inline vec3 ray_at(const ray_t *r, float t) { return v_add(r->origin, v_mulf(r->dir, t)); }
+
+/* ------------------------------------------------------------ hit record */
+/* src/geometry/mod.rs:22-27, default :36-39 */
+typedef struct { vec3 p, normal; float t; int front_face; } hit_record;
+
+/* src/geometry/mod.rs:30-33 */
+static inline void set_face_normal(hit_record *hr, const ray_t *ray, vec3 outward) {
+    hr->front_face = v_dot(ray->dir, outward) < 0.0f;
+    hr->normal = hr->front_face ? outward : v_neg(outward);
+}
+
+/* --------------------------------------------------------- scene storage */
+typedef struct { int32_t kind; vec3 albedo; float param; } material_t;
+
+enum { K_SPHERE = 0, K_PLANE = 1, K_CUBE = 2, K_TRI = 3 };
+
+typedef struct {
+    int kind;
+    uint32_t mat;
+    /* sphere: a = center, f0 = radius
+     * plane:  a = normal, b = point
+     * cube:   a = center, f0,f1,f2 = w,h,d, b = corner0, c = corner1
+     * tri:    a = v0, b = e1, c = e2 */
+    vec3 a, b, c;
+    float f0, f1, f2;
+} prim_t;
+
+typedef struct {
+    uint32_t n;
+    prim_t *list; /* insertion order of HittableList, src/geometry/mod.rs:228-238 */
+    uint32_t n_mat;
+    material_t *mats;
+} scene_t;
+
+static void scene_free(scene_t *s) { free(s->list); free(s->mats); s->list = NULL; s->mats = NULL; }
+
+/* Rebuild the insertion-ordered list from the per-kind arrays of rt_scene. */
+static int scene_build(const rt_scene *in, scene_t *out) {
+    uint64_t n64 = (uint64_t)in->n_spheres + in->n_planes + in->n_cubes + in->n_tris;
+    if (n64 > 0x7fffffffu) return RT_E_BADARG;
+    uint32_t n = (uint32_t)n64;
+    out->n = n;
+    out->n_mat = in->n_materials;
+    out->list = (prim_t *)calloc(n ? n : 1, sizeof(prim_t));
+    out->mats = (material_t *)calloc(in->n_materials ? in->n_materials : 1, sizeof(material_t));
+    uint8_t *seen = (uint8_t *)calloc(n ? n : 1, 1);
+    if (!out->list || !out->mats || !seen) { free(seen); scene_free(out); return RT_E_OOM; }
+    for (uint32_t m = 0; m < in->n_materials; ++m) {
+        out->mats[m].kind = in->mat_kind[m];
+        out->mats[m].albedo = v3(in->mat_r[m], in->mat_g[m], in->mat_b[m]);
+        out->mats[m].param = in->mat_param[m];
+        if (in->mat_kind[m] < 0 || in->mat_kind[m] > 2) { free(seen); scene_free(out); return RT_E_BADARG; }
+    }
+    int bad = 0;
+#define PLACE(id, matidx)                                                         \
+    if ((id) >= n || seen[(id)] || (matidx) >= in->n_materials) { bad = 1; break; } \
+    seen[(id)] = 1;                                                               \
+    prim_t *p = &out->list[(id)];                                                 \
+    p->mat = (matidx);
+    for (uint32_t k = 0; k < in->n_spheres; ++k) {
+        PLACE(in->sph_id[k], in->sph_mat[k])
+        p->kind = K_SPHERE;
+        p->a = v3(in->sph_cx[k], in->sph_cy[k], in->sph_cz[k]);
+        p->f0 = in->sph_r[k];
+    }
+    for (uint32_t k = 0; !bad && k < in->n_planes; ++k) {
+        PLACE(in->pl_id[k], in->pl_mat[k])
+        p->kind = K_PLANE;
+        p->a = v3(in->pl_nx[k], in->pl_ny[k], in->pl_nz[k]);
+        p->b = v3(in->pl_px[k], in->pl_py[k], in->pl_pz[k]);
+    }
+    for (uint32_t k = 0; !bad && k < in->n_cubes; ++k) {
+        PLACE(in->cb_id[k], in->cb_mat[k])
+        p->kind = K_CUBE;
+        p->a = v3(in->cb_cx[k], in->cb_cy[k], in->cb_cz[k]);
+        p->f0 = in->cb_w[k]; p->f1 = in->cb_h[k]; p->f2 = in->cb_d[k];
+        /* Cube::new, src/geometry/mod.rs:146-154 */
+        p->b = v_add(p->a, v3(-p->f0 / 2.0f, -p->f1 / 2.0f, -p->f2 / 2.0f));
+        p->c = v_add(p->a, v3(p->f0 / 2.0f, p->f1 / 2.0f, p->f2 / 2.0f));
+    }
+    for (uint32_t k = 0; !bad && k < in->n_tris; ++k) {
+        PLACE(in->tri_id[k], in->tri_mat[k])
+        p->kind = K_TRI;
+        vec3 v0 = v3(in->tri_v0x[k], in->tri_v0y[k], in->tri_v0z[k]);
+        vec3 v1 = v3(in->tri_v1x[k], in->tri_v1y[k], in->tri_v1z[k]);
+        vec3 v2 = v3(in->tri_v2x[k], in->tri_v2y[k], in->tri_v2z[k]);
+        p->a = v0; p->b = v_sub(v1, v0); p->c = v_sub(v2, v0);
+    }
+#undef PLACE
+    free(seen);
+    if (bad) { scene_free(out); return RT_E_BADARG; }
+    return RT_OK;
+}
+
+/* --------------------------------------------------------------- sampler */
+typedef struct {
+    int mode;
+    const float *disc;   /* 64 x 2,  src/denoising/mod.rs:55 */
+    const float *sphere; /* 256 x 3, src/denoising/mod.rs:59 */
+    const float *screen; /* 128*128, src/denoising/mod.rs:61 */
+    uint32_t counter_disc;   /* src/denoising/mod.rs:54 */
+    uint32_t counter_sphere; /* src/denoising/mod.rs:53 (REF_SEQ) */
+    uint64_t pcg_state;      /* REF_SEQ stand-in for thread_rng */
+    /* DET: per-path state */
+    uint32_t path_key, path_counter, bounce;
+    uint64_t segments;
+} sampler_t;
+
+/* 32-bit integer mixer shared with the GPU library (two multiply-xorshift
+ * rounds); any bijection with good avalanche would do, both sides use this one */
+static inline uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+#define GOLDEN32 0x9E3779B9u
+
+static inline uint32_t pcg32(uint64_t *state) {
+    uint64_t old = *state;
+    *state = old * 6364136223846793005ULL + 1442695040888963407ULL;
+    uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+    uint32_t rot = (uint32_t)(old >> 59u);
+    return (xs >> rot) | (xs << ((-rot) & 31));
+}
+
+/* src/denoising/mod.rs:12-18 */
+static inline void random_in_disc(sampler_t *sm, float *a, float *b) {
+    sm->counter_disc = sm->counter_disc + 1;
+    uint32_t k = sm->counter_disc % 64u;
+    *a = sm->disc[2 * k];
+    *b = sm->disc[2 * k + 1];
+}
+/* src/denoising/mod.rs:19-23: i is the column, j the row from the bottom */
+static inline float get_screenspace(const sampler_t *sm, uint32_t i, uint32_t j) {
+    uint32_t idx = 128u * (i % 128u) + (j % 128u);
+    return sm->screen[idx];
+}
+/* src/denoising/mod.rs:37-50: (table[seed % 256] * sp_bn) * 1.1 */
+static inline vec3 random_in_unit_sphere(sampler_t *sm, uint32_t pi, uint32_t pj) {
+    uint32_t seed;
+    if (sm->mode == ORC_MODE_REF_SEQ) {
+        sm->counter_sphere = sm->counter_sphere + 1;
+        seed = sm->counter_sphere;
+    } else {
+        seed = sm->path_counter + 1; /* committed by ray_colour for the closest hit only */
+    }
+    float sp_bn = get_screenspace(sm, pi, pj);
+    uint32_t k = seed % 256u;
+    vec3 t = v3(sm->sphere[3 * k], sm->sphere[3 * k + 1], sm->sphere[3 * k + 2]);
+    return v_mulf(v_mulf(t, sp_bn), 1.1f);
+}
+/* `rand::thread_rng().gen::<f32>()`, src/geometry/mod.rs:319: 24 random bits
+ * scaled into [0,1) as rand 0.8 does; the bit source is ours */
+static inline float coin(sampler_t *sm) {
+    uint32_t r;
+    if (sm->mode == ORC_MODE_REF_SEQ) r = pcg32(&sm->pcg_state);
+    else r = mix32(sm->path_key + GOLDEN32 * (sm->bounce + 1u));
+    return (float)(r >> 8) * (1.0f / 16777216.0f);
+}
+
+/* ------------------------------------------------------------- materials */
+/* src/geometry/mod.rs:274-281 */
+static void scatter_metal(const material_t *m, const ray_t *r_in, ray_t *r_out, const hit_record *hr,
+                          vec3 *att, sampler_t *sm, uint32_t pi, uint32_t pj) {
+    vec3 reflected = v_reflect(v_unit(r_in->dir), hr->normal);
+    *att = m->albedo;
+    r_out->origin = hr->p;
+    r_out->dir = v_add(reflected, v_mulf(random_in_unit_sphere(sm, pi, pj), m->param));
+}
+/* src/geometry/mod.rs:287-299 */
+static void scatter_lambertian(const material_t *m, ray_t *r_out, const hit_record *hr, vec3 *att,
+                               sampler_t *sm, uint32_t pi, uint32_t pj) {
+    vec3 scatter_dir = v_add(hr->normal, random_in_unit_sphere(sm, pi, pj));
+    if (v_is_near_zero(scatter_dir)) scatter_dir = hr->normal;
+    *att = m->albedo;
+    r_out->origin = hr->p;
+    r_out->dir = scatter_dir;
+}
+/* src/geometry/mod.rs:307-312 */
+static vec3 refract(vec3 uv, vec3 n, float etai_over_etat) {
+    float cos_theta = f_min(v_dot(v_neg(uv), n), 1.0f);
+    vec3 r_out_perp = v_mulf(v_add(uv, v_mulf(n, cos_theta)), etai_over_etat);
+    vec3 r_out_parallel = v_mulf(v_neg(n), sqrtf(fabsf(1.0f - v_len2(r_out_perp))));
+    return v_add(r_out_perp, r_out_parallel);
+}
+/* f32::powi(2) and powi(5) as LLVM expands them: x*x and x*((x*x)*(x*x)) */
+static inline float powi2(float x) { return x * x; }
+static inline float powi5(float x) { float x2 = x * x; float x4 = x2 * x2; return x * x4; }
+/* src/geometry/mod.rs:313-317 */
+static float reflectance(float cosine, float ref_idx) {
+    float r0 = powi2((1.0f - ref_idx) / (1.0f + ref_idx));
+    return r0 + (1.0f - r0) * powi5(1.0f - cosine);
+}
+/* src/geometry/mod.rs:323-346 */
+static void scatter_dielectric(const material_t *m, const ray_t *r_in, ray_t *r_out,
+                               const hit_record *hr, vec3 *att, sampler_t *sm) {
+    *att = m->albedo;
+    float refraction_ratio = hr->front_face ? 1.0f / m->param : m->param;
+    vec3 unit_dir = v_unit(r_in->dir);
+    float cos_theta = f_min(v_dot(v_neg(unit_dir), hr->normal), 1.0f);
+    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    vec3 dir;
+    /* `||` short-circuits: the coin is drawn only when refraction is possible */
+    if (refraction_ratio * sin_theta > 1.0f || reflectance(cos_theta, refraction_ratio) > coin(sm))
+        dir = v_reflect(unit_dir, hr->normal);
+    else
+        dir = refract(unit_dir, hr->normal, refraction_ratio);
+    r_out->origin = hr->p;
+    r_out->dir = dir;
+}
+/* dyn Material dispatch, src/geometry/mod.rs:264-266 */
+static void scatter(const scene_t *sc, uint32_t mat, const ray_t *r_in, ray_t *r_out,
+                    const hit_record *hr, vec3 *att, sampler_t *sm, uint32_t pi, uint32_t pj) {
+    const material_t *m = &sc->mats[mat];
+    if (m->kind == RT_METAL) scatter_metal(m, r_in, r_out, hr, att, sm, pi, pj);
+    else if (m->kind == RT_LAMBERTIAN) scatter_lambertian(m, r_out, hr, att, sm, pi, pj);
+    else scatter_dielectric(m, r_in, r_out, hr, att, sm);
+}
+
+/* ------------------------------------------------------------ primitives */
+/* Sphere::hit, src/geometry/mod.rs:60-94 */
+static int sphere_hit(const scene_t *sc, const prim_t *s, const ray_t *ray, vec3 *att, float t_min,
+                      float t_max, hit_record *hr, ray_t *r_out, sampler_t *sm, uint32_t pi,
+                      uint32_t pj) {
+    vec3 oc = v_sub(ray->origin, s->a);
+    float a = v_len2(ray->dir);
+    float half_b = v_dot(oc, ray->dir);
+    float c = v_len2(oc) - s->f0 * s->f0;
+    float discriminant = half_b * half_b - a * c;
+    if (discriminant < 0.0f) return 0;
+    float d_sqrt = sqrtf(discriminant);
+    float root = -(half_b + d_sqrt) / a;
+    if (root < t_min || t_max < root) {
+        root = (-half_b + d_sqrt) / a;
+        if (root < t_min || t_max < root) return 0;
+    }
+    hr->t = root;
+    hr->p = ray_at(ray, hr->t);
+    hr->normal = v_divf(v_sub(hr->p, s->a), s->f0);
+    vec3 outward = v_divf(v_sub(hr->p, s->a), s->f0);
+    set_face_normal(hr, ray, outward);
+    *r_out = *ray;
+    scatter(sc, s->mat, ray, r_out, hr, att, sm, pi, pj);
+    return 1;
+}
+/* Plane::hit, src/geometry/mod.rs:112-130: t is stored before the range test;
+ * a NaN t fails both comparisons and is accepted */
+static int plane_hit(const scene_t *sc, const prim_t *pl, const ray_t *ray, vec3 *att, float t_min,
+                     float t_max, hit_record *hr, ray_t *r_out, sampler_t *sm, uint32_t pi,
+                     uint32_t pj) {
+    hr->t = v_dot(v_sub(pl->b, ray->origin), pl->a) / v_dot(pl->a, ray->dir);
+    if (hr->t < t_min || hr->t > t_max) return 0;
+    hr->p = ray_at(ray, hr->t);
+    hr->normal = pl->a;
+    set_face_normal(hr, ray, hr->normal);
+    *r_out = *ray;
+    scatter(sc, pl->mat, ray, r_out, hr, att, sm, pi, pj);
+    return 1;
+}
+/* Cube::hit, src/geometry/mod.rs:158-223: slab test; t = tmin even when that
+ * lies before t_min; no set_face_normal, so front_face keeps whatever the
+ * shared temp record last held */
+static int cube_hit(const scene_t *sc, const prim_t *cb, const ray_t *ray, vec3 *att, float t_min,
+                    float t_max, hit_record *hr, ray_t *r_out, sampler_t *sm, uint32_t pi,
+                    uint32_t pj) {
+    float tmin, tmax, tymin, tymax, tzmin, tzmax;
+    vec3 c0 = cb->b, c1 = cb->c;
+    if (ray->dir.x >= 0.0f) {
+        tmin = (c0.x - ray->origin.x) / ray->dir.x;
+        tmax = (c1.x - ray->origin.x) / ray->dir.x;
+    } else {
+        tmin = (c1.x - ray->origin.x) / ray->dir.x;
+        tmax = (c0.x - ray->origin.x) / ray->dir.x;
+    }
+    if (ray->dir.y >= 0.0f) {
+        tymin = (c0.y - ray->origin.y) / ray->dir.y;
+        tymax = (c1.y - ray->origin.y) / ray->dir.y;
+    } else {
+        tymin = (c1.y - ray->origin.y) / ray->dir.y;
+        tymax = (c0.y - ray->origin.y) / ray->dir.y;
+    }
+    if ((tmin > tymax) || (tymin > tmax)) return 0;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    if (ray->dir.z >= 0.0f) {
+        tzmin = (c0.z - ray->origin.z) / ray->dir.z;
+        tzmax = (c1.z - ray->origin.z) / ray->dir.z;
+    } else {
+        tzmin = (c1.z - ray->origin.z) / ray->dir.z;
+        tzmax = (c0.z - ray->origin.z) / ray->dir.z;
+    }
+    if ((tmin > tzmax) || (tzmin > tmax)) return 0;
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    if (tmin < t_max && tmax > t_min) {
+        *r_out = *ray;
+        hr->t = tmin;
+        hr->p = ray_at(ray, hr->t);
+        const float eps = 1.0001f;
+        vec3 pc = v_sub(hr->p, cb->a);
+        hr->normal.x = (float)f_to_i32(eps * pc.x / (cb->f0 / 2.0f));
+        hr->normal.y = (float)f_to_i32(eps * pc.y / (cb->f1 / 2.0f));
+        hr->normal.z = (float)f_to_i32(eps * pc.z / (cb->f2 / 2.0f));
+        hr->normal = v_unit(hr->normal);
+        scatter(sc, cb->mat, ray, r_out, hr, att, sm, pi, pj);
+        return 1;
+    }
+    return 0;
+}
+/* Triangle: defined by rt_hip.h, not by the reference */
+static int tri_hit(const scene_t *sc, const prim_t *tr, const ray_t *ray, vec3 *att, float t_min,
+                   float t_max, hit_record *hr, ray_t *r_out, sampler_t *sm, uint32_t pi,
+                   uint32_t pj) {
+    vec3 h = v_cross(ray->dir, tr->c);
+    float det = v_dot(tr->b, h);
+    if (det == 0.0f) return 0;
+    float f = 1.0f / det;
+    vec3 s = v_sub(ray->origin, tr->a);
+    float u = f * v_dot(s, h);
+    if (u < 0.0f || u > 1.0f) return 0;
+    vec3 q = v_cross(s, tr->b);
+    float v = f * v_dot(ray->dir, q);
+    if (v < 0.0f || u + v > 1.0f) return 0;
+    float t = f * v_dot(tr->c, q);
+    if (t < t_min || t_max < t) return 0;
+    hr->t = t;
+    hr->p = ray_at(ray, t);
+    vec3 outward = v_unit(v_cross(tr->b, tr->c));
+    set_face_normal(hr, ray, outward);
+    *r_out = *ray;
+    scatter(sc, tr->mat, ray, r_out, hr, att, sm, pi, pj);
+    return 1;
+}
+
+/* HittableList::hit, src/geometry/mod.rs:240-258 */
+static int list_hit(const scene_t *sc, const ray_t *ray, vec3 *att, float t_min, float t_max,
+                    hit_record *hr, ray_t *r_out, int32_t *hit_index, sampler_t *sm, uint32_t pi,
+                    uint32_t pj) {
+    hit_record temp_hr = {{0, 0, 0}, {0, 0, 0}, 0.0f, 1};
+    float closest_so_far = t_max;
+    int have = 0;
+    for (uint32_t k = 0; k < sc->n; ++k) {
+        const prim_t *o = &sc->list[k];
+        ray_t r;
+        int got;
+        switch (o->kind) {
+        case K_SPHERE: got = sphere_hit(sc, o, ray, att, t_min, closest_so_far, &temp_hr, &r, sm, pi, pj); break;
+        case K_PLANE:  got = plane_hit(sc, o, ray, att, t_min, closest_so_far, &temp_hr, &r, sm, pi, pj); break;
+        case K_CUBE:   got = cube_hit(sc, o, ray, att, t_min, closest_so_far, &temp_hr, &r, sm, pi, pj); break;
+        default:       got = tri_hit(sc, o, ray, att, t_min, closest_so_far, &temp_hr, &r, sm, pi, pj); break;
+        }
+        if (got) {
+            closest_so_far = temp_hr.t;
+            hr->p = temp_hr.p;
+            hr->normal = temp_hr.normal;
+            hr->t = temp_hr.t;
+            hr->front_face = temp_hr.front_face;
+            *r_out = r;
+            *hit_index = (int32_t)k;
+            have = 1;
+        }
+    }
+    return have;
+}
+
+/* ----------------------------------------------------------- ray_colour */
+typedef struct {
+    const scene_t *sc;
+    sampler_t *sm;
+    uint32_t max_bounces;
+    int gamma;
+    float t_min;
+} trace_env;
+
+/* ray_colour, src/raytracer.rs:68-92 */
+static vec3 ray_colour(const trace_env *env, const ray_t *ray, uint32_t ray_bounces, uint32_t pi,
+                       uint32_t pj, int32_t *first_id) {
+    if (ray_bounces <= 0) return v3(0.0f, 0.0f, 0.0f);
+    hit_record hr = {{0, 0, 0}, {0, 0, 0}, 0.0f, 1};
+    vec3 attenuation = v3(0.0f, 0.0f, 0.0f);
+    ray_t r;
+    int32_t idx = -1;
+    sampler_t *sm = env->sm;
+    sm->bounce = env->max_bounces - ray_bounces;
+    sm->segments += 1;
+    int got = list_hit(env->sc, ray, &attenuation, env->t_min, INFINITY, &hr, &r, &idx, sm, pi, pj);
+    if (first_id) *first_id = got ? idx : -1;
+    if (got) {
+        if (sm->mode == ORC_MODE_DET) {
+            int32_t k = env->sc->mats[env->sc->list[idx].mat].kind;
+            if (k == RT_METAL || k == RT_LAMBERTIAN) sm->path_counter += 1;
+        }
+        vec3 rest = ray_colour(env, &r, ray_bounces - 1, pi, pj, NULL);
+        return v_mulv(attenuation, rest);
+    }
+    vec3 unit_dir = v_unit(ray->dir);
+    float t = 0.5f * unit_dir.y + 1.0f;
+    vec3 colour = v_add(v_mulf(v3(1.0f, 1.0f, 1.0f), 1.0f - t), v_mulf(v3(0.5f, 0.7f, 1.0f), t));
+    if (env->gamma) {
+        colour.x = sqrtf(colour.x);
+        colour.y = sqrtf(colour.y);
+        colour.z = sqrtf(colour.z);
+    }
+    return colour;
+}
+
+/* ---------------------------------------------------------------- camera */
+/* Camera::get_ray, src/camera/mod.rs:75-79 */
+static ray_t get_ray(const rt_camera *cam, float s, float t, vec3 disk) {
+    vec3 origin = v3(cam->origin[0], cam->origin[1], cam->origin[2]);
+    vec3 llc = v3(cam->lower_left_corner[0], cam->lower_left_corner[1], cam->lower_left_corner[2]);
+    vec3 hor = v3(cam->horizontal[0], cam->horizontal[1], cam->horizontal[2]);
+    vec3 ver = v3(cam->vertical[0], cam->vertical[1], cam->vertical[2]);
+    vec3 u = v3(cam->u[0], cam->u[1], cam->u[2]);
+    vec3 v = v3(cam->v[0], cam->v[1], cam->v[2]);
+    vec3 rd = v_mulf(disk, cam->lens_radius);
+    vec3 offset = v_add(v_mulf(u, rd.x), v_mulf(v, rd.y));
+    ray_t r;
+    r.origin = v_add(origin, offset);
+    r.dir = v_sub(v_sub(v_add(v_add(llc, v_mulf(hor, s)), v_mulf(ver, t)), origin), offset);
+    return r;
+}
+
+/* Camera::new, src/camera/mod.rs:35-73 (deg_to_rad :30-32) */
+int orc_camera_new(float v_fov, float aspect_ratio, float aperture, float focus_dist,
+                   const float origin_[3], const float look_at_[3], const float v_up_[3],
+                   rt_camera *out) {
+    vec3 origin = v3(origin_[0], origin_[1], origin_[2]);
+    vec3 look_at = v3(look_at_[0], look_at_[1], look_at_[2]);
+    vec3 v_up = v3(v_up_[0], v_up_[1], v_up_[2]);
+    float theta = v_fov * 3.14159265358979323846264338327950288f / 180.0f;
+    float h = tanf(theta / 2.0f);
+    float viewport_height = 2.0f * h;
+    float viewport_width = aspect_ratio * viewport_height;
+    vec3 w = v_unit(v_sub(origin, look_at));
+    vec3 u = v_unit(v_cross(v_up, w));
+    vec3 v = v_cross(w, u);
+    vec3 horizontal = v_mulf(v_mulf(u, viewport_width), focus_dist);
+    vec3 vertical = v_mulf(v_mulf(v, viewport_height), focus_dist);
+    vec3 llc = v_sub(v_sub(v_sub(origin, v_divf(horizontal, 2.0f)), v_divf(vertical, 2.0f)),
+                     v_mulf(w, focus_dist));
+    out->origin[0] = origin.x; out->origin[1] = origin.y; out->origin[2] = origin.z;
+    out->lower_left_corner[0] = llc.x; out->lower_left_corner[1] = llc.y; out->lower_left_corner[2] = llc.z;
+    out->horizontal[0] = horizontal.x; out->horizontal[1] = horizontal.y; out->horizontal[2] = horizontal.z;
+    out->vertical[0] = vertical.x; out->vertical[1] = vertical.y; out->vertical[2] = vertical.z;
+    out->u[0] = u.x; out->u[1] = u.y; out->u[2] = u.z;
+    out->v[0] = v.x; out->v[1] = v.y; out->v[2] = v.z;
+    out->lens_radius = aperture / 2.0f;
+    return RT_OK;
+}
+
+/* Scene::get_camera, src/scene/mod.rs:59-76, with COUNTER (:87) and the
+ * aperture (:70) as arguments */
+int orc_scene_camera(uint32_t counter, float aperture, rt_camera *out) {
+    vec3 cam_origin = v_sub(v3(1.0f, 1.30f, 4.0f), v3(0.0f, 0.0f, (float)counter * 0.1f));
+    vec3 look_at = v3(0.25f, 0.60f, -0.50f);
+    float o[3] = {cam_origin.x, cam_origin.y, cam_origin.z};
+    float l[3] = {look_at.x, look_at.y, look_at.z};
+    float up[3] = {0.0f, 1.0f, 0.0f};
+    return orc_camera_new(27.0f, 16.0f / 9.0f, aperture, v_len(v_sub(cam_origin, look_at)), o, l, up, out);
+}
+
+/* src/raytracer.rs:118-120 */
+uint32_t orc_image_height(uint32_t width, float aspect_ratio) {
+    float h = (float)width / aspect_ratio;
+    if (h != h || h <= 0.0f) return 0;
+    if (h >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)h;
+}
+
+/* -------------------------------------------------------------- quantiser */
+/* clamp, src/raytracer.rs:35-39 */
+static inline float clampf(float x, float lo, float hi) {
+    if (x < lo) return lo;
+    if (x > hi) return hi;
+    return x;
+}
+/* write_colour + from_u8_rgb, src/raytracer.rs:41-55; accum is {r,g,b,n} per pixel */
+void orc_pack(const float *accum_rgbn, size_t n_px, uint32_t *out) {
+    for (size_t k = 0; k < n_px; ++k) {
+        const float *c = accum_rgbn + 4 * k;
+        float scale = 1.0f / c[3];
+        uint32_t ir = f_to_u8(256.0f * clampf(c[0] * scale, 0.0f, 0.999f));
+        uint32_t ig = f_to_u8(256.0f * clampf(c[1] * scale, 0.0f, 0.999f));
+        uint32_t ib = f_to_u8(256.0f * clampf(c[2] * scale, 0.0f, 0.999f));
+        out[k] = (ir << 16) | (ig << 8) | ib;
+    }
+}
+
+/* ------------------------------------------------------------ render loop */
+typedef struct {
+    const scene_t *sc;
+    const rt_camera *cam;
+    const float *disc, *sphere, *screen;
+    rt_params p;
+    int mode;
+    uint32_t thread_id, num_threads;
+    float *accum;          /* 4 floats per pixel, display order */
+    int32_t *primary_ids;  /* may be NULL */
+    uint64_t segments;
+    /* REF_SEQ: state carried from call to call */
+    uint32_t counter_disc, counter_sphere;
+    uint64_t pcg_state;
+} worker_t;
+
+/* calculate_some_pxls, src/raytracer.rs:232-271.  Rows are interleaved over the
+ * workers like `(thread_id..image_height).step_by(num_threads)` (:245); on top
+ * of that only rows whose 8-row band is selected by band_begin/band_stride are
+ * rendered, and only samples [sample_begin, sample_begin+sample_count). */
+static void *worker_main(void *arg) {
+    worker_t *wk = (worker_t *)arg;
+    const rt_params *p = &wk->p;
+    sampler_t sm;
+    memset(&sm, 0, sizeof sm);
+    sm.mode = wk->mode;
+    sm.disc = wk->disc; sm.sphere = wk->sphere; sm.screen = wk->screen;
+    sm.counter_disc = wk->counter_disc;
+    sm.counter_sphere = wk->counter_sphere;
+    sm.pcg_state = wk->pcg_state;
+    trace_env env = {wk->sc, &sm, p->max_bounces, p->gamma != 0, p->t_min};
+    const uint32_t W = p->width, H = p->height;
+    for (uint32_t j = wk->thread_id; j < H; j += wk->num_threads) {
+        if ((j / RT_BAND_ROWS) % p->band_stride != p->band_begin) continue;
+        for (uint32_t i = 0; i < W; ++i) {
+            vec3 px_colour = v3(0.0f, 0.0f, 0.0f);
+            uint32_t row = H - 1 - j;
+            float *acc = wk->accum + 4 * ((size_t)row * W + i);
+            /* continue the running sum of earlier calls: the reference adds all
+             * samples of a pixel into one accumulator (:249,262) */
+            px_colour = v3(acc[0], acc[1], acc[2]);
+            for (uint32_t s = p->sample_begin; s < p->sample_begin + p->sample_count; ++s) {
+                if (sm.mode == ORC_MODE_DET) {
+                    uint64_t n = ((uint64_t)j * W + i) * p->spp + s;
+                    sm.counter_disc = (uint32_t)(2u * n);
+                    uint32_t pix = j * W + i;
+                    sm.path_key = mix32(pix ^ mix32(s ^ (p->seed * GOLDEN32)));
+                    sm.path_counter = sm.path_key;
+                }
+                float ox, oy, a, b;
+                random_in_disc(&sm, &ox, &oy);
+                float u = ((float)i + ox) / (float)(W - 1);
+                float v = ((float)j + oy) / (float)(H - 1);
+                random_in_disc(&sm, &a, &b);
+                ray_t r = get_ray(wk->cam, u, v, v3(a, b, 0.0f));
+                int32_t first = -1;
+                int want_id = (s == 0 && wk->primary_ids != NULL);
+                vec3 c = ray_colour(&env, &r, p->max_bounces, i, j, want_id ? &first : NULL);
+                if (want_id) wk->primary_ids[(size_t)row * W + i] = first;
+                px_colour = v_add(px_colour, c);
+            }
+            acc[0] = px_colour.x; acc[1] = px_colour.y; acc[2] = px_colour.z;
+            acc[3] = acc[3] + (float)p->sample_count;
+        }
+    }
+    wk->segments = sm.segments;
+    wk->counter_disc = sm.counter_disc;
+    wk->counter_sphere = sm.counter_sphere;
+    wk->pcg_state = sm.pcg_state;
+    return NULL;
+}
+
+/* Persistent REF_SEQ counters (the reference's `static mut`, src/denoising/mod.rs:53-54) */
+typedef struct { uint32_t counter_disc, counter_sphere; uint64_t pcg_state; } orc_seq_state;
+
+/*
+ * Render into accum (4 floats per pixel {r,g,b,n}, display order, added to).
+ * mode ORC_MODE_REF_SEQ runs on one thread whatever n_threads says, because
+ * the counters it models are a single global sequence; seq (may be NULL = start
+ * from zero) carries them across calls.
+ */
+int orc_render(const rt_scene *scene, const rt_camera *cam, const float *disc, const float *sphere,
+               const float *screen, const rt_params *params, int mode, uint32_t n_threads,
+               float *accum, int32_t *primary_ids, uint64_t *segments, orc_seq_state *seq) {
+    if (!scene || !cam || !disc || !sphere || !screen || !params || !accum) return RT_E_BADARG;
+    if (params->width < 2 || params->height < 2 || params->band_stride == 0 ||
+        params->band_begin >= params->band_stride || params->max_bounces > RT_MAX_BOUNCES)
+        return RT_E_BADARG;
+    if ((uint64_t)params->sample_begin + params->sample_count > params->spp) return RT_E_BADARG;
+    scene_t sc;
+    int rc = scene_build(scene, &sc);
+    if (rc != RT_OK) return rc;
+    if (mode == ORC_MODE_REF_SEQ || n_threads == 0) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    worker_t *wk = (worker_t *)calloc(n_threads, sizeof(worker_t));
+    pthread_t *th = (pthread_t *)calloc(n_threads, sizeof(pthread_t));
+    if (!wk || !th) { free(wk); free(th); scene_free(&sc); return RT_E_OOM; }
+    for (uint32_t k = 0; k < n_threads; ++k) {
+        wk[k].sc = &sc; wk[k].cam = cam;
+        wk[k].disc = disc; wk[k].sphere = sphere; wk[k].screen = screen;
+        wk[k].p = *params; wk[k].mode = mode;
+        wk[k].thread_id = k; wk[k].num_threads = n_threads;
+        wk[k].accum = accum; wk[k].primary_ids = primary_ids;
+        if (seq) {
+            wk[k].counter_disc = seq->counter_disc;
+            wk[k].counter_sphere = seq->counter_sphere;
+            wk[k].pcg_state = seq->pcg_state;
+        } else {
+            wk[k].pcg_state = 0x853c49e6748fea9bULL ^ params->seed;
+        }
+    }
+    if (n_threads == 1) {
+        worker_main(&wk[0]);
+    } else {
+        for (uint32_t k = 0; k < n_threads; ++k) pthread_create(&th[k], NULL, worker_main, &wk[k]);
+        for (uint32_t k = 0; k < n_threads; ++k) pthread_join(th[k], NULL);
+    }
+    uint64_t total = 0;
+    for (uint32_t k = 0; k < n_threads; ++k) total += wk[k].segments;
+    if (segments) *segments += total;
+    if (seq && mode == ORC_MODE_REF_SEQ) {
+        seq->counter_disc = wk[0].counter_disc;
+        seq->counter_sphere = wk[0].counter_sphere;
+        seq->pcg_state = wk[0].pcg_state;
+    }
+    free(wk); free(th);
+    scene_free(&sc);
+    return RT_OK;
+}
+
+/*
+ * One HittableList::hit + scatter for a caller-supplied ray: the unit the
+ * known-answer tests poke.  out[0..15] = {hit(0/1), index, t, front_face,
+ * p.xyz, normal.xyz, scattered.dir.xyz, attenuation.rgb}; the scattered origin
+ * equals p.  sphere_tick is the value the unit-sphere counter has BEFORE the
+ * call (the lookup uses sphere_tick+1).
+ */
+int orc_trace_one(const rt_scene *scene, const float *sphere_tbl, const float *screen_tbl,
+                  const float origin[3], const float dir[3], float t_min, float t_max,
+                  uint32_t pix_i, uint32_t pix_j, uint32_t sphere_tick, float *out16) {
+    scene_t sc;
+    int rc = scene_build(scene, &sc);
+    if (rc != RT_OK) return rc;
+    sampler_t sm;
+    memset(&sm, 0, sizeof sm);
+    sm.mode = ORC_MODE_REF_SEQ;
+    sm.sphere = sphere_tbl; sm.screen = screen_tbl;
+    sm.counter_sphere = sphere_tick;
+    sm.pcg_state = 0x853c49e6748fea9bULL;
+    ray_t ray = {v3(origin[0], origin[1], origin[2]), v3(dir[0], dir[1], dir[2])};
+    hit_record hr = {{0, 0, 0}, {0, 0, 0}, 0.0f, 1};
+    vec3 att = v3(0, 0, 0);
+    ray_t r = ray;
+    int32_t idx = -1;
+    int got = list_hit(&sc, &ray, &att, t_min, t_max, &hr, &r, &idx, &sm, pix_i, pix_j);
+    out16[0] = (float)got; out16[1] = (float)idx; out16[2] = hr.t; out16[3] = (float)hr.front_face;
+    out16[4] = hr.p.x; out16[5] = hr.p.y; out16[6] = hr.p.z;
+    out16[7] = hr.normal.x; out16[8] = hr.normal.y; out16[9] = hr.normal.z;
+    out16[10] = r.dir.x; out16[11] = r.dir.y; out16[12] = r.dir.z;
+    out16[13] = att.x; out16[14] = att.y; out16[15] = att.z;
+    scene_free(&sc);
+    return RT_OK;
+}
+
+/* Camera::get_ray for the known-answer tests: out6 = origin, dir */
+void orc_get_ray(const rt_camera *cam, float s, float t, float disk_a, float disk_b, float *out6) {
+    ray_t r = get_ray(cam, s, t, v3(disk_a, disk_b, 0.0f));
+    out6[0] = r.origin.x; out6[1] = r.origin.y; out6[2] = r.origin.z;
+    out6[3] = r.dir.x; out6[4] = r.dir.y; out6[5] = r.dir.z;
+}
+
+/* the sky branch of ray_colour (src/raytracer.rs:81-91) for the tests */
+void orc_sky(const float dir[3], int gamma, float *out3) {
+    scene_t sc = {0, NULL, 0, NULL};
+    sampler_t sm;
+    memset(&sm, 0, sizeof sm);
+    trace_env env = {&sc, &sm, 1, gamma, 0.001f};
+    ray_t ray = {v3(0, 0, 0), v3(dir[0], dir[1], dir[2])};
+    vec3 c = ray_colour(&env, &ray, 1, 0, 0, NULL);
+    out3[0] = c.x; out3[1] = c.y; out3[2] = c.z;
+}

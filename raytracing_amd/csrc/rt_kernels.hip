@@ -1,0 +1,479 @@
+// rt_kernels.hip - the render loop as gfx950 (CDNA4, wave64) kernels.
+//
+// One wavefront renders one 8x8 pixel tile, one lane per pixel.  A lane walks
+// its samples one after the other; as soon as a path ends (sky or depth budget)
+// the lane starts its next sample, so a wave stays full until the tail of the
+// sample range.  The closest-hit scan runs over the primitive list in the
+// reference's insertion order with a wave-uniform loop counter: primitive data
+// is read through scalar loads into SGPRs and every lane tests the same
+// primitive against its own ray, so the scan has no divergence between lanes
+// that are tracing.  Arithmetic that decides a result is plain f32 mul/add/div/
+// sqrt without contraction (the reference is scalar Rust f32,
+// src/vector/mod.rs:141-189); fused multiply-add is used only in the
+// conservative sphere rejection test, which can never change a result.
+//
+// Reference lines each device function follows are cited at the function.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_device.h"
+
+namespace rtk {
+
+// ------------------------------------------------------------------ vec3
+// src/vector/mod.rs:12-16 and the operator impls :107-189
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float t) { return mk(a.x * t, a.y * t, a.z * t); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator/(V3 a, float t) { return mk(a.x / t, a.y / t, a.z / t); }
+// src/vector/mod.rs:34-36: (x*x + y*y) + z*z, three roundings for the products
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float len2(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+// src/vector/mod.rs:38-42
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// src/vector/mod.rs:44-46: true division by the rounded length
+__device__ __forceinline__ V3 unit(V3 a) { return a / __builtin_sqrtf(len2(a)); }
+// src/vector/mod.rs:91-93
+__device__ __forceinline__ V3 reflect(V3 v, V3 n) { return v - (n * 2.0f) * dot(v, n); }
+// Rust f32::min
+__device__ __forceinline__ float rmin(float a, float b) {
+    if (a != a) return b;
+    if (b != b) return a;
+    return a < b ? a : b;
+}
+// Rust `as i32`
+__device__ __forceinline__ float trunc_i32_as_f32(float x) {
+    if (x != x) return 0.0f;
+    if (x >= 2147483648.0f) return 2147483648.0f;   // (i32::MAX as f32) rounds to 2^31
+    if (x <= -2147483648.0f) return -2147483648.0f;
+    return (float)(int32_t)x;
+}
+
+// integer mixer of the sampling schedule (two multiply-xorshift rounds)
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+constexpr uint32_t GOLDEN32 = 0x9E3779B9u;
+
+// Scene arrays are read through the constant address space: together with a
+// wave-uniform index this makes the compiler fetch them with scalar loads
+// (s_load_dwordx4 into SGPRs) instead of 64 identical vector loads.  The arrays
+// are never written while a render kernel runs.
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+#define RT_CONST_AS __attribute__((address_space(4)))
+template <typename T, typename S>
+__device__ __forceinline__ const RT_CONST_AS T *const_ptr(const S *p) {
+    return (const RT_CONST_AS T *)(uintptr_t)p;
+}
+struct SceneView {
+    const RT_CONST_AS u4 *runs;
+    const RT_CONST_AS f4 *sph_geom, *sph_cull, *planes, *cubes, *tris, *mat_albedo;
+    const RT_CONST_AS uint32_t *sph_mat;
+    const RT_CONST_AS int32_t *mat_kind;
+    uint32_t n_runs, need_ff_shared;
+};
+__device__ __forceinline__ SceneView view_of(const DevScene &sc) {
+    SceneView v;
+    v.runs = const_ptr<u4>(sc.runs);
+    v.sph_geom = const_ptr<f4>(sc.sph_geom);
+    v.sph_cull = const_ptr<f4>(sc.sph_cull);
+    v.planes = const_ptr<f4>(sc.planes);
+    v.cubes = const_ptr<f4>(sc.cubes);
+    v.tris = const_ptr<f4>(sc.tris);
+    v.mat_albedo = const_ptr<f4>(sc.mat_albedo);
+    v.sph_mat = const_ptr<uint32_t>(sc.sph_mat);
+    v.mat_kind = const_ptr<int32_t>(sc.mat_kind);
+    v.n_runs = sc.n_runs;
+    v.need_ff_shared = sc.need_ff_shared;
+    return v;
+}
+
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int TILE = 8;   // 8x8 pixels per wavefront
+
+struct Lds {
+    float disc[128];                                    // src/denoising/mod.rs:55
+    float sphere[768];                                  // src/denoising/mod.rs:59
+    uint32_t mat_stack[WAVES_PER_BLOCK][RT_MAX_BOUNCES][64];
+};
+
+struct Ray { V3 o, d; };
+
+// Camera::get_ray, src/camera/mod.rs:75-79
+__device__ __forceinline__ Ray get_ray(const rt_camera &c, float s, float t, float da, float db) {
+    V3 origin = mk(c.origin[0], c.origin[1], c.origin[2]);
+    V3 llc = mk(c.lower_left_corner[0], c.lower_left_corner[1], c.lower_left_corner[2]);
+    V3 hor = mk(c.horizontal[0], c.horizontal[1], c.horizontal[2]);
+    V3 ver = mk(c.vertical[0], c.vertical[1], c.vertical[2]);
+    V3 cu = mk(c.u[0], c.u[1], c.u[2]);
+    V3 cv = mk(c.v[0], c.v[1], c.v[2]);
+    V3 rd = mk(da, db, 0.0f) * c.lens_radius;
+    V3 offset = cu * rd.x + cv * rd.y;
+    Ray r;
+    r.o = origin + offset;
+    r.d = llc + hor * s + ver * t - origin - offset;
+    return r;
+}
+
+// BlueNoise::random_in_unit_sphere, src/denoising/mod.rs:37-50: (v*sp_bn)*1.1
+__device__ __forceinline__ V3 rius(const Lds &lds, uint32_t seed, float sp_bn) {
+    uint32_t k = seed & 255u;
+    V3 t = mk(lds.sphere[3 * k], lds.sphere[3 * k + 1], lds.sphere[3 * k + 2]);
+    return (t * sp_bn) * 1.1f;
+}
+
+// f32::powi(5) as LLVM expands it
+__device__ __forceinline__ float powi5(float x) { float x2 = x * x; float x4 = x2 * x2; return x * x4; }
+
+struct Hit {
+    float t;        // closest_so_far, src/geometry/mod.rs:242
+    int kind;       // -1 = nothing hit
+    uint32_t slot;  // position in the kind's device array
+    int32_t id;     // position in the reference's list
+    bool ff;        // front_face as the shared temp record held it at accept time
+};
+
+// ----------------------------------------------------------------------
+// HittableList::hit, src/geometry/mod.rs:240-258, without the scatter calls:
+// scatter results of hits that do not end up closest are discarded by the
+// reference, so only (t, primitive, front_face) is tracked here and the record
+// of the final hit is rebuilt afterwards from the same inputs.
+// ----------------------------------------------------------------------
+__device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, float t_min, Hit &h) {
+    h.t = __builtin_inff();
+    h.kind = -1;
+    h.slot = 0;
+    h.id = -1;
+    h.ff = true;
+    bool ff_shared = true;   // temp_hr.front_face, default true (src/geometry/mod.rs:36-39,241)
+    const float a = len2(ray.d);   // Sphere::hit :63, the same for every sphere
+    for (uint32_t r = 0; r < sc.n_runs; ++r) {
+        const u4 run = sc.runs[r];   // {kind, first, count, id0}
+        if (run.x == DEV_SPHERE) {
+            // Sphere::hit, src/geometry/mod.rs:60-94
+            for (uint32_t k = 0; k < run.z; ++k) {
+                const f4 g = sc.sph_geom[run.y + k];   // cx, cy, cz, radius
+                V3 oc = ray.o - mk(g.x, g.y, g.z);
+                float half_b = dot(oc, ray.d);
+                float c = len2(oc) - g.w * g.w;
+                float disc = half_b * half_b - a * c;
+                if (disc < 0.0f) continue;
+                float d_sqrt = __builtin_sqrtf(disc);
+                float root = -(half_b + d_sqrt) / a;
+                if (root < t_min || h.t < root) {
+                    root = (-half_b + d_sqrt) / a;
+                    if (root < t_min || h.t < root) continue;
+                }
+                h.t = root; h.kind = DEV_SPHERE; h.slot = run.y + k; h.id = (int32_t)(run.w + k);
+                if (sc.need_ff_shared) {
+                    V3 p = ray.o + ray.d * root;
+                    V3 outward = (p - mk(g.x, g.y, g.z)) / g.w;
+                    ff_shared = dot(ray.d, outward) < 0.0f;
+                }
+            }
+        } else if (run.x == DEV_PLANE) {
+            // Plane::hit, src/geometry/mod.rs:112-130
+            for (uint32_t k = 0; k < run.z; ++k) {
+                const f4 n4 = sc.planes[2 * (run.y + k)];
+                const f4 p4 = sc.planes[2 * (run.y + k) + 1];
+                V3 n = mk(n4.x, n4.y, n4.z);
+                float t = dot(mk(p4.x, p4.y, p4.z) - ray.o, n) / dot(n, ray.d);
+                if (t < t_min || t > h.t) continue;
+                h.t = t; h.kind = DEV_PLANE; h.slot = run.y + k; h.id = (int32_t)(run.w + k);
+                if (sc.need_ff_shared) ff_shared = dot(ray.d, n) < 0.0f;
+            }
+        } else if (run.x == DEV_CUBE) {
+            // Cube::hit, src/geometry/mod.rs:158-223
+            for (uint32_t k = 0; k < run.z; ++k) {
+                const f4 c0 = sc.cubes[4 * (run.y + k) + 2];
+                const f4 c1 = sc.cubes[4 * (run.y + k) + 3];
+                float tmin, tmax, tymin, tymax, tzmin, tzmax;
+                if (ray.d.x >= 0.0f) { tmin = (c0.x - ray.o.x) / ray.d.x; tmax = (c1.x - ray.o.x) / ray.d.x; }
+                else                 { tmin = (c1.x - ray.o.x) / ray.d.x; tmax = (c0.x - ray.o.x) / ray.d.x; }
+                if (ray.d.y >= 0.0f) { tymin = (c0.y - ray.o.y) / ray.d.y; tymax = (c1.y - ray.o.y) / ray.d.y; }
+                else                 { tymin = (c1.y - ray.o.y) / ray.d.y; tymax = (c0.y - ray.o.y) / ray.d.y; }
+                if ((tmin > tymax) || (tymin > tmax)) continue;
+                if (tymin > tmin) tmin = tymin;
+                if (tymax < tmax) tmax = tymax;
+                if (ray.d.z >= 0.0f) { tzmin = (c0.z - ray.o.z) / ray.d.z; tzmax = (c1.z - ray.o.z) / ray.d.z; }
+                else                 { tzmin = (c1.z - ray.o.z) / ray.d.z; tzmax = (c0.z - ray.o.z) / ray.d.z; }
+                if ((tmin > tzmax) || (tzmin > tmax)) continue;
+                if (tzmin > tmin) tmin = tzmin;
+                if (tzmax < tmax) tmax = tzmax;
+                if (tmin < h.t && tmax > t_min) {
+                    h.t = tmin; h.kind = DEV_CUBE; h.slot = run.y + k; h.id = (int32_t)(run.w + k);
+                    h.ff = ff_shared;   // no set_face_normal in Cube::hit
+                }
+            }
+        } else {
+            // Triangle (defined by rt_hip.h, absent from the reference)
+            for (uint32_t k = 0; k < run.z; ++k) {
+                const f4 v0 = sc.tris[3 * (run.y + k)];
+                const f4 e1 = sc.tris[3 * (run.y + k) + 1];
+                const f4 e2 = sc.tris[3 * (run.y + k) + 2];
+                V3 E1 = mk(e1.x, e1.y, e1.z), E2 = mk(e2.x, e2.y, e2.z);
+                V3 hh = cross(ray.d, E2);
+                float det = dot(E1, hh);
+                if (det == 0.0f) continue;
+                float f = 1.0f / det;
+                V3 s = ray.o - mk(v0.x, v0.y, v0.z);
+                float u = f * dot(s, hh);
+                if (u < 0.0f || u > 1.0f) continue;
+                V3 q = cross(s, E1);
+                float v = f * dot(ray.d, q);
+                if (v < 0.0f || u + v > 1.0f) continue;
+                float t = f * dot(E2, q);
+                if (t < t_min || h.t < t) continue;
+                h.t = t; h.kind = DEV_TRI; h.slot = run.y + k; h.id = (int32_t)(run.w + k);
+                if (sc.need_ff_shared) {
+                    V3 outward = unit(cross(E1, E2));
+                    ff_shared = dot(ray.d, outward) < 0.0f;
+                }
+            }
+        }
+    }
+}
+
+// Rebuild the HitRecord of the closest hit (p, normal, front_face) exactly as
+// the primitive's hit() filled it, then run its material's scatter.
+// Returns the material index; ray is replaced by the scattered ray.
+__device__ __forceinline__ uint32_t shade_hit(const SceneView &sc, const Lds &lds, Ray &ray, const Hit &h,
+                                              float sp_bn, uint32_t &path_counter, uint32_t path_key,
+                                              uint32_t bounce) {
+    V3 p = ray.o + ray.d * h.t;   // Ray::at, src/ray/mod.rs:19-21
+    V3 normal;
+    bool ff = h.ff;
+    uint32_t mat;
+    if (h.kind == DEV_SPHERE) {
+        // src/geometry/mod.rs:81-86
+        const f4 g = sc.sph_geom[h.slot];
+        V3 outward = (p - mk(g.x, g.y, g.z)) / g.w;
+        ff = dot(ray.d, outward) < 0.0f;
+        normal = ff ? outward : -outward;
+        mat = sc.sph_mat[h.slot];
+    } else if (h.kind == DEV_PLANE) {
+        // src/geometry/mod.rs:120-123
+        const f4 n4 = sc.planes[2 * h.slot];
+        V3 outward = mk(n4.x, n4.y, n4.z);
+        ff = dot(ray.d, outward) < 0.0f;
+        normal = ff ? outward : -outward;
+        mat = __float_as_uint(n4.w);
+    } else if (h.kind == DEV_CUBE) {
+        // src/geometry/mod.rs:208-216
+        const f4 cc = sc.cubes[4 * h.slot];
+        const f4 hw = sc.cubes[4 * h.slot + 1];   // w/2, h/2, d/2
+        const float eps = 1.0001f;
+        V3 pc = p - mk(cc.x, cc.y, cc.z);
+        V3 nn;
+        nn.x = trunc_i32_as_f32(eps * pc.x / hw.x);
+        nn.y = trunc_i32_as_f32(eps * pc.y / hw.y);
+        nn.z = trunc_i32_as_f32(eps * pc.z / hw.z);
+        normal = unit(nn);
+        mat = __float_as_uint(cc.w);
+    } else {
+        const f4 v0 = sc.tris[3 * h.slot];
+        const f4 e1 = sc.tris[3 * h.slot + 1];
+        const f4 e2 = sc.tris[3 * h.slot + 2];
+        V3 outward = unit(cross(mk(e1.x, e1.y, e1.z), mk(e2.x, e2.y, e2.z)));
+        ff = dot(ray.d, outward) < 0.0f;
+        normal = ff ? outward : -outward;
+        mat = __float_as_uint(v0.w);
+    }
+    const f4 ma = sc.mat_albedo[mat];   // r, g, b, param
+    const int mk_ = sc.mat_kind[mat];
+    V3 dir;
+    if (mk_ == RT_METAL) {
+        // Metal::scatter, src/geometry/mod.rs:274-281
+        V3 reflected = reflect(unit(ray.d), normal);
+        path_counter += 1;
+        dir = reflected + rius(lds, path_counter, sp_bn) * ma.w;
+    } else if (mk_ == RT_LAMBERTIAN) {
+        // Lambertian::scatter, src/geometry/mod.rs:287-299
+        path_counter += 1;
+        dir = normal + rius(lds, path_counter, sp_bn);
+        if (dir.x < 0.0f && dir.y < 0.0f && dir.z < 0.0f) dir = normal;   // is_near_zero, src/vector/mod.rs:29-32
+    } else {
+        // Dielectric::scatter, src/geometry/mod.rs:323-346
+        float ratio = ff ? 1.0f / ma.w : ma.w;
+        V3 ud = unit(ray.d);
+        float cos_theta = rmin(dot(-ud, normal), 1.0f);
+        float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+        bool refl = ratio * sin_theta > 1.0f;
+        if (!refl) {
+            // reflectance, src/geometry/mod.rs:313-317; coin: hash of (path, bounce)
+            float r0 = (1.0f - ratio) / (1.0f + ratio);
+            r0 = r0 * r0;
+            float refl_p = r0 + (1.0f - r0) * powi5(1.0f - cos_theta);
+            uint32_t rb = mix32(path_key + GOLDEN32 * (bounce + 1u));
+            float coin = (float)(rb >> 8) * (1.0f / 16777216.0f);
+            refl = refl_p > coin;
+        }
+        if (refl) {
+            dir = reflect(ud, normal);
+        } else {
+            // refract, src/geometry/mod.rs:307-312
+            float ct = rmin(dot(-ud, normal), 1.0f);
+            V3 perp = (ud + normal * ct) * ratio;
+            V3 par = (-normal) * __builtin_sqrtf(__builtin_fabsf(1.0f - len2(perp)));
+            dir = perp + par;
+        }
+    }
+    ray.o = p;
+    ray.d = dir;
+    return mat;
+}
+
+// sky branch of ray_colour, src/raytracer.rs:81-91
+__device__ __forceinline__ V3 sky(V3 d, bool gamma) {
+    V3 ud = unit(d);
+    float t = 0.5f * ud.y + 1.0f;
+    V3 c = mk(1.0f, 1.0f, 1.0f) * (1.0f - t) + mk(0.5f, 0.7f, 1.0f) * t;
+    if (gamma) { c.x = __builtin_sqrtf(c.x); c.y = __builtin_sqrtf(c.y); c.z = __builtin_sqrtf(c.z); }
+    return c;
+}
+
+// ----------------------------------------------------------------------
+// calculate_some_pxls + ray_colour, src/raytracer.rs:232-271 and :68-92.
+// grid.x = ceil(W / 32) (four 8x8 tiles side by side per workgroup),
+// grid.y = number of 8-row bands this call renders.
+// ----------------------------------------------------------------------
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64)
+void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
+    __shared__ Lds lds;
+    const SceneView sc = view_of(dsc);
+    for (uint32_t k = threadIdx.x; k < 128; k += blockDim.x) lds.disc[k] = fr.tbl_disc[k];
+    for (uint32_t k = threadIdx.x; k < 768; k += blockDim.x) lds.sphere[k] = fr.tbl_sphere[k];
+    __syncthreads();
+
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t W = p.width, H = p.height;
+    const uint32_t band = p.band_begin + blockIdx.y * p.band_stride;
+    const uint32_t i = (blockIdx.x * WAVES_PER_BLOCK + wave) * TILE + (lane & 7u);   // column
+    const uint32_t j = band * TILE + (lane >> 3);                                    // row from the bottom
+    const bool inside = i < W && j < H;
+    const uint32_t row = H - 1u - j;                                                 // src/raytracer.rs:265
+    const size_t pix_out = (size_t)row * W + i;
+    const uint32_t pix = j * W + i;
+    const uint32_t s_end = p.sample_begin + p.sample_count;
+    const bool gamma = p.gamma != 0;
+
+    float sp_bn = 0.0f;
+    V3 px = mk(0.0f, 0.0f, 0.0f);
+    float n_prev = 0.0f;
+    if (inside) {
+        // BlueNoise::get_screenspace, src/denoising/mod.rs:19-23: fixed per pixel
+        sp_bn = fr.tbl_screen[128u * (i % 128u) + (j % 128u)];
+        float4 acc = fr.accum[pix_out];
+        px = mk(acc.x, acc.y, acc.z);
+        n_prev = acc.w;
+    }
+
+    uint32_t s = p.sample_begin;
+    bool alive = inside && p.sample_count > 0 && p.max_bounces > 0;
+    Ray ray;
+    ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1);
+    uint32_t depth_left = p.max_bounces, n_stack = 0, path_key = 0, path_counter = 0;
+    uint32_t n_seg = 0;
+
+    auto start_sample = [&]() {
+        // two disc draws per sample: jitter then lens (src/raytracer.rs:254,258);
+        // sample n of a single-thread run uses entries 2n+1 and 2n+2 of the
+        // pre-incremented counter (src/denoising/mod.rs:13-17)
+        uint32_t n = pix * p.spp + s;   // only n mod 32 matters, wrap is harmless
+        uint32_t k1 = (2u * n + 1u) & 63u, k2 = (2u * n + 2u) & 63u;
+        float ox = lds.disc[2 * k1], oy = lds.disc[2 * k1 + 1];
+        float la = lds.disc[2 * k2], lb = lds.disc[2 * k2 + 1];
+        float u = ((float)i + ox) / (float)(W - 1u);
+        float v = ((float)j + oy) / (float)(H - 1u);
+        ray = get_ray(cam, u, v, la, lb);
+        path_key = mix32(pix ^ mix32(s ^ (p.seed * GOLDEN32)));
+        path_counter = path_key;
+        depth_left = p.max_bounces;
+        n_stack = 0;
+    };
+    if (alive) start_sample();
+
+    while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
+        Hit h;
+        scan_list(sc, ray, p.t_min, h);
+        n_seg += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(alive));
+        if (alive) {
+            if (s == 0u && n_stack == 0u) fr.primary_ids[pix_out] = h.id;
+            bool done;
+            V3 c;
+            if (h.kind >= 0) {
+                uint32_t bounce = p.max_bounces - depth_left;
+                uint32_t mat = shade_hit(sc, lds, ray, h, sp_bn, path_counter, path_key, bounce);
+                lds.mat_stack[wave][n_stack][lane] = mat;
+                n_stack += 1;
+                depth_left -= 1;
+                done = depth_left == 0u;   // `if ray_bounces <= 0 { return 0 }`, src/raytracer.rs:69
+                c = mk(0.0f, 0.0f, 0.0f);
+            } else {
+                c = sky(ray.d, gamma);
+                done = true;
+            }
+            if (done) {
+                // attenuation * ray_colour(...), innermost product first (src/raytracer.rs:79)
+                for (uint32_t k = n_stack; k-- > 0u;) {
+                    const f4 ma = sc.mat_albedo[lds.mat_stack[wave][k][lane]];
+                    c = mk(ma.x, ma.y, ma.z) * c;
+                }
+                px = px + c;   // src/raytracer.rs:262
+                s += 1;
+                if (s < s_end) start_sample();
+                else alive = false;
+            }
+        }
+    }
+
+    if (inside) {
+        fr.accum[pix_out] = make_float4(px.x, px.y, px.z, n_prev + (float)p.sample_count);
+    }
+    if (lane == 0 && n_seg != 0) atomicAdd(fr.segments, (unsigned long long)n_seg);
+}
+
+// write_colour + from_u8_rgb, src/raytracer.rs:35-55
+__device__ __forceinline__ uint32_t quantise(float x) {
+    if (x < 0.0f) x = 0.0f;
+    else if (x > 0.999f) x = 0.999f;
+    float y = 256.0f * x;
+    if (y != y) return 0u;          // Rust `as u8`: NaN -> 0, saturating
+    if (y >= 255.0f) return 255u;
+    if (y <= 0.0f) return 0u;
+    return (uint32_t)(int32_t)y;
+}
+__global__ __launch_bounds__(256)
+void pack_0rgb(const float4 *__restrict__ accum, uint32_t *__restrict__ out, uint32_t n_px) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_px) return;
+    float4 a = accum[k];
+    float scale = 1.0f / a.w;
+    uint32_t r = quantise(a.x * scale), g = quantise(a.y * scale), b = quantise(a.z * scale);
+    out[k] = (r << 16) | (g << 8) | b;
+}
+
+}  // namespace rtk
+
+// ------------------------------------------------------------ launchers
+hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_params &p,
+                             const DevFrame &fr, uint32_t n_bands, hipStream_t stream) {
+    dim3 grid((p.width + 31u) / 32u, n_bands, 1), block(rtk::WAVES_PER_BLOCK * 64, 1, 1);
+    hipLaunchKernelGGL(rtk::render_tiles, grid, block, 0, stream, sc, cam, p, fr);
+    return hipGetLastError();
+}
+hipError_t rtk_launch_pack(const float4 *accum, uint32_t *out, uint32_t n_px, hipStream_t stream) {
+    dim3 grid((n_px + 255u) / 256u, 1, 1), block(256, 1, 1);
+    hipLaunchKernelGGL(rtk::pack_0rgb, grid, block, 0, stream, accum, out, n_px);
+    return hipGetLastError();
+}
