@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py - throughput of the render loop on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4] [--spp-per-step 16]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one pass of the hot path over the whole frame: `spp-per-step` samples
+of every pixel, added into the per-pixel sums (the progressive form of
+calculate_some_pxls, src/raytracer.rs:232-271), followed by the quantiser and,
+with N > 1 GPUs, one RCCL all-gather of the packed bands.  The default workload
+is the one the headline metric is quoted on: 10,000 random spheres at 3840x2160,
+256 spp; with the defaults (16 steps of 16 spp) the timed region is exactly one
+such frame.  The frame is split over the N ranks by interleaved 8-row bands
+(strong scaling: the total work is fixed).
+
+Rank 0 prints ONE JSON line.  `value` is Mrays/s over all ranks, a ray being one
+path segment (one closest-hit query over the list), counted on the device.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+# FP32 vector peak of MI355X: 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz, FMA = 2 FLOP
+PEAK_FP32_VECTOR_TFLOPS = 157.3
+# the same issue rate with one flop per instruction: the reference's arithmetic
+# has no fused multiply-add, so a literal evaluation cannot exceed this
+PEAK_FP32_NOFMA_TFLOPS = PEAK_FP32_VECTOR_TFLOPS / 2.0
+
+
+def cpu_baseline(wl, tables, budget_s=15.0):
+    """The CPU oracle (a C restatement of the reference's loop, row-interleaved
+    threads like src/raytracer.rs:245) on a bounded sample of the same workload:
+    1 spp of every 64th band of the frame, band after band until the time budget is used."""
+    from raytracing_amd import make_params
+    from tests import oracle_lib
+
+    orc = oracle_lib.load()
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16), 64)
+    w, h = wl["width"], wl["height"]
+    total_bands = (h + 7) // 8
+    stride = 64
+    accum = np.zeros((h, w, 4), dtype=np.float32)
+    seg = 0
+    bands = 0
+    t0 = time.perf_counter()
+    for begin in [32, 0, 48, 16, 8, 40, 24, 56] + [b for b in range(64) if b % 8]:
+        if begin >= total_bands:
+            continue
+        p = make_params(w, h, spp=wl["spp"], sample_begin=0, sample_count=1, band_begin=begin,
+                        band_stride=stride)
+        _, _, s = orc.render(wl["flat"], wl["camera"], tables, p, threads=cores, accum=accum, want_ids=False)
+        seg += s
+        bands += len(range(begin, total_bands, stride))
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(seg / dt / 1e6, 5), "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "sample": "%d of %d 8-row bands of the %dx%d frame at 1 of %d spp, %d segments in %.1f s"
+                  % (bands, total_bands, w, h, wl["spp"], seg, dt),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c4")
+    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: librt_hip.so has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from raytracing_amd import Renderer, load_tables, make_params
+    from raytracing_amd import workloads
+
+    tables = load_tables()
+    wl = workloads.workload(args.workload)
+    w, h, spp = wl["width"], wl["height"], wl["spp"]
+    sps = max(1, min(args.spp_per_step, spp))
+    total_bands = (h + 7) // 8
+    my_bands = len(range(rank, total_bands, world))
+    max_bands = len(range(0, total_bands, world))
+    flops_seg = workloads.flops_per_segment(wl["flat"])
+
+    r = Renderer(local_rank, tables)
+    r.set_scene(wl["flat"])
+    r.set_camera(wl["camera"])
+    r.begin_frame(w, h)
+    block = torch.zeros((max_bands * 8, w), dtype=torch.int32, device="cuda")
+    gathered = torch.zeros((world, max_bands * 8, w), dtype=torch.int32, device="cuda") if world > 1 else None
+
+    def step(k):
+        """samples [k*sps, (k+1)*sps) modulo the frame's spp, so any number of steps is valid"""
+        begin = (k % max(1, spp // sps)) * sps
+        p = make_params(w, h, spp=spp, sample_begin=begin, sample_count=sps, band_begin=rank,
+                        band_stride=world)
+        r.timer_start()
+        r.render(p)
+        ms = r.timer_stop()          # HIP events on the library's stream around the launch
+        r.export_packed_bands(block.data_ptr(), block.numel(), rank, world)
+        r.sync()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, block)
+        return ms
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    r.begin_frame(w, h)              # timed steps start from zeroed sums
+    barrier()
+    seg0 = r.ray_count()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        kernel_ms.append(step(k))
+    barrier()
+    dt = time.perf_counter() - t0
+    seg = r.ray_count() - seg0
+
+    if world > 1:
+        t = torch.tensor([dt, float(seg), float(np.mean(kernel_ms))], dtype=torch.float64, device="cuda")
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0]); seg_total = int(tsum[1]); kern_ms_max = float(tmax[2])
+    else:
+        seg_total = seg; kern_ms_max = float(np.mean(kernel_ms))
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        paths = w * h * sps * args.steps
+        # roofline of the dominant kernel (render_tiles) on THIS rank: algorithmic
+        # flops of its segments / its mean launch duration (HIP events)
+        achieved = flops_seg * (seg / args.steps) / (np.mean(kernel_ms) * 1e-3) / 1e12
+        out = {
+            "metric": "Mrays/s (whole node) + ms/frame at 4K 256spp, 1/2/4/8 MI355X",
+            "value": round(seg_total / dt / 1e6, 3),
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s: %s" % (args.workload, wl["description"]),
+                "spp_per_step": sps, "steps_per_frame": spp // sps,
+                "ms_per_frame": round(ms_per_step * (spp / sps), 1),
+                "mpaths_per_s": round(paths / dt / 1e6, 3),
+                "segments_per_path": round(seg_total / paths, 4),
+                "partition": "interleaved 8-row bands, rank r renders bands r, r+N, ...; "
+                             "RCCL all_gather of packed pixels per step" if world > 1 else "single GPU",
+                "sampling": "deterministic schedule (RT_SAMPLING_DET), seed 0",
+            },
+            "roofline": {
+                "bound": "valu", "achieved": round(float(achieved), 3), "peak": PEAK_FP32_VECTOR_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(float(achieved) / PEAK_FP32_VECTOR_TFLOPS, 4),
+                "traffic": None,
+                "kernel": "render_tiles", "kernel_ms": round(float(np.mean(kernel_ms)), 3),
+                "flops_per_segment": flops_seg,
+                "frac_of_no_fma_ceiling": round(float(achieved) / PEAK_FP32_NOFMA_TFLOPS, 4),
+                "note": "algorithmic flops (mul/add counted singly, no FMA in the reference) of the "
+                        "segments one launch traces / mean launch time from HIP events; peak = FP32 "
+                        "vector peak with FMA counted as 2",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, tables)
+        print(json.dumps(out), flush=True)
+
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

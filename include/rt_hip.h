@@ -171,6 +171,16 @@ int rt_ray_count(rt_ctx *ctx, uint64_t *segments);
  * rt_destroy.  accum: float4 {r,g,b,n} per pixel; packed: uint32 per pixel;
  * ids: int32 per pixel; all in display order.  stream: the hipStream_t. */
 int rt_device_buffers(rt_ctx *ctx, void **accum, void **packed, void **ids, void **stream);
+/* quantise (write_colour, src/raytracer.rs:46-55) the bands b with
+ * b % band_stride == band_begin straight into dst_device (device memory of the
+ * caller, capacity_px pixels) as one compact block: the k-th such band occupies
+ * rows 8k..8k+7 of the block, the row with the smallest j (lowest on screen)
+ * first, width pixels per row; rows above the top of the image are zero.  This
+ * is what one GPU contributes to a multi-GPU gather, like one worker's share of
+ * the channel fan-in, src/raytracer.rs:176-185.  Asynchronous on the context's
+ * stream. */
+int rt_export_packed_bands(rt_ctx *ctx, uint32_t *dst_device, size_t capacity_px,
+                           uint32_t band_begin, uint32_t band_stride);
 /* HIP-event stopwatch on the context's stream; stop synchronises */
 int rt_timer_start(rt_ctx *ctx);
 int rt_timer_stop(rt_ctx *ctx, float *milliseconds);

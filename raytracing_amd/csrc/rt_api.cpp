@@ -90,6 +90,12 @@ inline float bits_to_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return
 
 struct ListEntry { int kind = -1; uint32_t k = 0; };
 
+// number of 8-row bands b < ceil(H/8) with b % stride == begin
+uint32_t bands_of(uint32_t height, uint32_t begin, uint32_t stride) {
+    const uint32_t total = (height + RT_BAND_ROWS - 1u) / RT_BAND_ROWS;
+    return total > begin ? (total - begin + stride - 1u) / stride : 0u;
+}
+
 }  // namespace
 
 extern "C" {
@@ -326,9 +332,7 @@ int rt_render(rt_ctx *ctx, const rt_params *p) {
         return fail(c, RT_E_BADARG, "rt_render: sample range exceeds spp");
     if (p->sampling_mode != RT_SAMPLING_DET) return fail(c, RT_E_BADARG, "rt_render: unknown sampling_mode");
     if (!(p->t_min == p->t_min)) return fail(c, RT_E_BADARG, "rt_render: t_min is NaN");
-    const uint32_t total_bands = (p->height + RT_BAND_ROWS - 1u) / RT_BAND_ROWS;
-    const uint32_t n_bands = total_bands > p->band_begin
-                                 ? (total_bands - p->band_begin + p->band_stride - 1u) / p->band_stride : 0u;
+    const uint32_t n_bands = bands_of(p->height, p->band_begin, p->band_stride);
     if (n_bands == 0 || p->sample_count == 0) return RT_OK;
     if (n_bands > 65535u) return fail(c, RT_E_BADARG, "rt_render: too many bands for one launch");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -424,6 +428,24 @@ int rt_device_buffers(rt_ctx *ctx, void **accum, void **packed, void **ids, void
     if (packed) *packed = c->d_packed;
     if (ids) *ids = c->d_ids;
     if (stream) *stream = c->stream;
+    return RT_OK;
+}
+
+int rt_export_packed_bands(rt_ctx *ctx, uint32_t *dst_device, size_t capacity_px, uint32_t band_begin,
+                           uint32_t band_stride) {
+    Ctx *c = C(ctx);
+    if (!c) return RT_E_BADARG;
+    if (!c->have_frame) return fail(c, RT_E_STATE, "rt_export_packed_bands: no frame");
+    if (!dst_device || band_stride == 0 || band_begin >= band_stride)
+        return fail(c, RT_E_BADARG, "rt_export_packed_bands: null destination or band_begin >= band_stride");
+    const uint32_t n_bands = bands_of(c->H, band_begin, band_stride);
+    if ((size_t)n_bands * RT_BAND_ROWS * c->W > capacity_px)
+        return fail(c, RT_E_BADARG, "rt_export_packed_bands: destination too small");
+    if (n_bands == 0) return RT_OK;
+    if (n_bands * RT_BAND_ROWS > 65535u) return fail(c, RT_E_BADARG, "rt_export_packed_bands: too many rows");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, rtk_launch_pack_bands(c->d_accum, dst_device, c->W, c->H, band_begin, band_stride, n_bands,
+                                     c->stream));
     return RT_OK;
 }
 

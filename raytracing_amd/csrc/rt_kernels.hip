@@ -463,9 +463,35 @@ void pack_0rgb(const float4 *__restrict__ accum, uint32_t *__restrict__ out, uin
     out[k] = (r << 16) | (g << 8) | b;
 }
 
+// pack_0rgb for the bands of one GPU, written as a compact block (8 rows per
+// band, lowest row first); see rt_export_packed_bands in rt_hip.h
+__global__ __launch_bounds__(256)
+void pack_bands(const float4 *__restrict__ accum, uint32_t *__restrict__ out, uint32_t W, uint32_t H,
+                uint32_t band_begin, uint32_t band_stride, uint32_t n_bands) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t m = blockIdx.y;                 // row of the block
+    if (x >= W || m >= n_bands * TILE) return;
+    const uint32_t j = (band_begin + (m / TILE) * band_stride) * TILE + (m % TILE);
+    uint32_t v = 0u;
+    if (j < H) {
+        float4 a = accum[(size_t)(H - 1u - j) * W + x];
+        float scale = 1.0f / a.w;
+        v = (quantise(a.x * scale) << 16) | (quantise(a.y * scale) << 8) | quantise(a.z * scale);
+    }
+    out[(size_t)m * W + x] = v;
+}
+
 }  // namespace rtk
 
 // ------------------------------------------------------------ launchers
+hipError_t rtk_launch_pack_bands(const float4 *accum, uint32_t *out, uint32_t W, uint32_t H,
+                                 uint32_t band_begin, uint32_t band_stride, uint32_t n_bands,
+                                 hipStream_t stream) {
+    dim3 grid((W + 255u) / 256u, n_bands * rtk::TILE, 1), block(256, 1, 1);
+    hipLaunchKernelGGL(rtk::pack_bands, grid, block, 0, stream, accum, out, W, H, band_begin, band_stride,
+                       n_bands);
+    return hipGetLastError();
+}
 hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_params &p,
                              const DevFrame &fr, uint32_t n_bands, hipStream_t stream) {
     dim3 grid((p.width + 31u) / 32u, n_bands, 1), block(rtk::WAVES_PER_BLOCK * 64, 1, 1);

@@ -161,6 +161,11 @@ class Renderer:
         self._check(self._lib.rt_ray_count(self._ctx, C.byref(v)))
         return v.value
 
+    def export_packed_bands(self, dst_device_ptr, capacity_px, band_begin, band_stride):
+        """quantise this GPU's bands into caller-owned device memory (compact block)"""
+        self._check(self._lib.rt_export_packed_bands(self._ctx, C.c_void_p(dst_device_ptr), capacity_px,
+                                                     band_begin, band_stride))
+
     def device_buffers(self):
         """raw device pointers (accum float4, packed u32, ids i32) and the hipStream_t"""
         ptrs = [C.c_void_p() for _ in range(4)]
