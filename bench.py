@@ -115,7 +115,7 @@ def main():
     r.set_camera(wl["camera"])
     r.begin_frame(w, h)
     block = torch.zeros((max_bands * 8, w), dtype=torch.int32, device="cuda")
-    gathered = torch.zeros((world, max_bands * 8, w), dtype=torch.int32, device="cuda") if world > 1 else None
+    gathered = torch.zeros((world * max_bands * 8, w), dtype=torch.int32, device="cuda") if world > 1 else None
 
     def step(k):
         """samples [k*sps, (k+1)*sps) modulo the frame's spp, so any number of steps is valid"""

@@ -1,0 +1,456 @@
+"""Known-answer tests that pin the CPU oracle.  The reference holds no tests or
+golden vectors, so every expected value here is derived by hand from the cited
+reference lines (ojferro/raytracing, paths relative to its root), with inputs
+chosen so the binary32 arithmetic is exact or easy to follow."""
+import math
+
+import numpy as np
+import pytest
+
+from raytracing_amd import (Cube, Dielectric, HittableList, Lambertian, Metal, Plane, Scene, Sphere,
+                            Triangle, image_height, make_params)
+from tests import oracle_lib
+
+f32 = np.float32
+INF = float("inf")
+
+
+def one(prim):
+    s = HittableList()
+    s.add(prim)
+    return s.flatten()
+
+
+def zero_screen(tables):
+    t = dict(tables)
+    t["screen"] = np.zeros(16384, dtype=np.float32)
+    return t
+
+
+# ---------------------------------------------------------------- Sphere
+def test_sphere_head_on_metal_mirror(oracle, tables):
+    """Sphere::hit src/geometry/mod.rs:60-94 + Metal::scatter :274-281.
+    Ray from (-0.8,0.5,1) down -z at the shiny sphere c=(-0.8,0.5,-1) r=0.5:
+    oc=(0,0,2), a=1, half_b=-2, c=4-0.25, disc=0.25, root=-(-2+0.5)/1=1.5."""
+    flat = one(Sphere((-0.8, 0.5, -1.0), 0.5, Metal((0.8, 0.8, 0.8), 0.0)))
+    r = oracle.trace_one(flat, tables, (-0.8, 0.5, 1.0), (0.0, 0.0, -1.0))
+    assert r["hit"] and r["index"] == 0
+    assert r["t"] == f32(1.5)
+    assert np.array_equal(r["p"], np.array([-0.8, 0.5, -0.5], dtype=f32))
+    assert np.array_equal(r["normal"], np.array([0, 0, 1], dtype=f32))
+    assert r["front_face"]
+    # reflect: v - (n*2)*dot(v,n) = (0,0,-1) - (0,0,2)*(-1) = (0,0,1); fuzz 0 adds 0
+    assert np.array_equal(r["dir"], np.array([0, 0, 1], dtype=f32))
+    assert np.array_equal(r["attenuation"], np.array([0.8, 0.8, 0.8], dtype=f32))
+
+
+def test_sphere_second_root_from_inside(oracle, tables):
+    """origin at the centre: first root -(0+r)/1 < t_min, second root (0+r)/1 is
+    taken (:73-79); outward normal points along the ray so front_face is false and
+    the stored normal is flipped (:30-33)."""
+    flat = one(Sphere((0.0, 0.0, 0.0), 0.5, Lambertian((0.5, 0.5, 0.5))))
+    r = oracle.trace_one(flat, zero_screen(tables), (0.0, 0.0, 0.0), (0.0, 0.0, -2.0))
+    assert r["hit"] and r["t"] == f32(0.25)          # sqrt(4*0.25)=1 -> 1/4
+    assert not r["front_face"]
+    assert np.array_equal(r["normal"], np.array([0, 0, 1], dtype=f32))
+
+
+def test_sphere_negative_radius_flips_normal(oracle, tables):
+    """radius -0.5: normal = (p-c)/radius points inward (:83-86), the hollow-glass trick of
+    src/scene/mod.rs:42-43.  Seen from outside that makes front_face false."""
+    flat = one(Sphere((0.0, 0.0, 0.0), -0.5, Dielectric((1.0, 1.0, 1.0), 1.5)))
+    r = oracle.trace_one(flat, tables, (0.0, 0.0, 2.0), (0.0, 0.0, -1.0))
+    assert r["hit"] and r["t"] == f32(1.5) and not r["front_face"]
+    assert np.array_equal(r["normal"], np.array([0, 0, 1], dtype=f32))   # -( (0,0,0.5)/-0.5 )
+
+
+def test_sphere_miss_and_behind(oracle, tables):
+    flat = one(Sphere((0.0, 0.0, 0.0), 0.5, Lambertian((0.5, 0.5, 0.5))))
+    assert not oracle.trace_one(flat, tables, (2.0, 0.0, 2.0), (0.0, 0.0, -1.0))["hit"]     # disc < 0
+    assert not oracle.trace_one(flat, tables, (0.0, 0.0, 2.0), (0.0, 0.0, 1.0))["hit"]      # both roots < t_min
+
+
+def test_sphere_tmax_is_inclusive(oracle, tables):
+    """`t_max < root` rejects, so root == t_max is accepted (:74)"""
+    flat = one(Sphere((0.0, 0.0, 0.0), 0.5, Lambertian((0.5, 0.5, 0.5))))
+    assert oracle.trace_one(flat, tables, (0, 0, 2.0), (0, 0, -1.0), t_max=1.5)["hit"]
+    assert not oracle.trace_one(flat, tables, (0, 0, 2.0), (0, 0, -1.0), t_max=1.4999999)["hit"]
+
+
+# ----------------------------------------------------------------- Plane
+def test_plane_hit_and_face(oracle, tables):
+    """Plane::hit :112-130: t = ((point-origin).n)/(n.dir)"""
+    flat = one(Plane((0.0, 1.0, 0.0), (0.0, 0.0, 0.0), Lambertian((0.3, 0.3, 0.3))))
+    r = oracle.trace_one(flat, zero_screen(tables), (0.0, 2.0, 0.0), (0.0, -4.0, 0.0))
+    assert r["hit"] and r["t"] == f32(0.5) and r["front_face"]
+    assert np.array_equal(r["normal"], np.array([0, 1, 0], dtype=f32))
+    below = oracle.trace_one(flat, zero_screen(tables), (0.0, -2.0, 0.0), (0.0, 4.0, 0.0))
+    assert below["hit"] and not below["front_face"]
+    assert np.array_equal(below["normal"], np.array([0, -1, 0], dtype=f32))
+
+
+def test_plane_parallel_is_inf_miss_and_nan_hit(oracle, tables):
+    flat = one(Plane((0.0, 1.0, 0.0), (0.0, 0.0, 0.0), Lambertian((0.3, 0.3, 0.3))))
+    # -2/0 = -inf < t_min -> miss;  2/0 from below = +inf > t_max? no: inf > inf is false -> accepted
+    assert not oracle.trace_one(flat, tables, (0.0, 2.0, 0.0), (1.0, 0.0, 0.0))["hit"]
+    r = oracle.trace_one(flat, tables, (0.0, -2.0, 0.0), (1.0, 0.0, 0.0))
+    assert r["hit"] and r["t"] == f32(INF)
+    # origin in the plane, direction parallel: 0/0 = NaN fails both comparisons -> a hit (:116)
+    r = oracle.trace_one(flat, tables, (0.0, 0.0, 0.0), (1.0, 0.0, 0.0))
+    assert r["hit"] and math.isnan(r["t"])
+
+
+def test_plane_tmax_inclusive(oracle, tables):
+    flat = one(Plane((0.0, 1.0, 0.0), (0.0, 0.0, 0.0), Lambertian((0.3, 0.3, 0.3))))
+    assert oracle.trace_one(flat, tables, (0, 2.0, 0), (0, -4.0, 0), t_max=0.5)["hit"]
+    assert not oracle.trace_one(flat, tables, (0, 2.0, 0), (0, -4.0, 0), t_max=0.49999997)["hit"]
+
+
+# ------------------------------------------------------------------ Cube
+CUBE = Cube((0.0, 0.5, -1.0), 0.5, 0.5, 0.5, Lambertian((0.7, 0.3, 0.7)))
+
+
+def test_cube_front_hit_normal(oracle, tables):
+    """Cube::hit :158-223.  Ray down -z through the centre line of the +z face:
+    slabs x,y give -inf..+inf style bounds (division by +-0), z gives
+    tmin = (-0.75-1)/-1 = 1.75.  normal = trunc(1.0001*(p-c)/(w/2)) = (0,0,1)."""
+    flat = one(CUBE)
+    r = oracle.trace_one(flat, zero_screen(tables), (0.0, 0.5, 1.0), (0.0, 0.0, -1.0))
+    assert r["hit"] and r["t"] == f32(1.75)
+    assert np.array_equal(r["p"], np.array([0, 0.5, -0.75], dtype=f32))
+    assert np.array_equal(r["normal"], np.array([0, 0, 1], dtype=f32))
+    assert r["front_face"]   # untouched default of the shared record (:36-39)
+
+
+def test_cube_inside_reports_negative_t(oracle, tables):
+    """origin inside the box: tmin < 0 is still reported (`tmin < t_max && tmax > t_min`, :205-208)"""
+    flat = one(CUBE)
+    r = oracle.trace_one(flat, zero_screen(tables), (0.0, 0.5, -1.0), (0.0, 0.0, -1.0))
+    assert r["hit"] and r["t"] == f32(-0.25)
+    assert np.array_equal(r["p"], np.array([0, 0.5, -0.75], dtype=f32))
+
+
+def test_cube_edge_gives_diagonal_normal(oracle, tables):
+    """a hit on the x/z edge truncates to (1,0,1) -> unit = (1/sqrt2, 0, 1/sqrt2) (:213-216)"""
+    flat = one(CUBE)
+    r = oracle.trace_one(flat, zero_screen(tables), (1.25, 0.5, 0.25), (-1.0, 0.0, -1.0))
+    assert r["hit"] and r["t"] == f32(1.0)
+    s = f32(1.0) / np.sqrt(f32(2.0))
+    assert np.array_equal(r["normal"], np.array([s, 0, s], dtype=f32))
+
+
+def test_cube_tie_keeps_earlier(oracle, tables):
+    """`tmin < t_max` is strict: a cube at exactly the current closest t loses"""
+    flat = one(CUBE)
+    assert not oracle.trace_one(flat, tables, (0.0, 0.5, 1.0), (0.0, 0.0, -1.0), t_max=1.75)["hit"]
+    assert oracle.trace_one(flat, tables, (0.0, 0.5, 1.0), (0.0, 0.0, -1.0), t_max=1.7500001)["hit"]
+
+
+def test_cube_inherits_front_face_from_previous_hit(oracle, tables):
+    """Cube::hit never calls set_face_normal; the list's shared temp record
+    (src/geometry/mod.rs:241) still holds the front_face of the last accepted
+    hit.  A sphere seen from inside (front_face=false) sits behind the cube in
+    space but before it in the list."""
+    s = HittableList()
+    s.add(Sphere((0.0, 0.5, 1.0), 5.0, Lambertian((0.5, 0.5, 0.5))))   # ray starts inside it
+    s.add(CUBE)
+    r = oracle.trace_one(s.flatten(), zero_screen(tables), (0.0, 0.5, 1.0), (0.0, 0.0, -1.0))
+    assert r["index"] == 1 and r["t"] == f32(1.75) and not r["front_face"]
+
+
+# ------------------------------------------------------------- list order
+def test_equal_t_later_sphere_and_plane_win(oracle, tables):
+    s = HittableList()
+    s.add(Sphere((0.0, 0.0, 0.0), 0.5, Lambertian((0.1, 0.1, 0.1))))
+    s.add(Sphere((0.0, 0.0, 0.0), 0.5, Lambertian((0.2, 0.2, 0.2))))
+    r = oracle.trace_one(s.flatten(), tables, (0, 0, 2.0), (0, 0, -1.0))
+    assert r["index"] == 1 and r["attenuation"][0] == f32(0.2)
+    s.add(Plane((0.0, 0.0, 1.0), (0.0, 0.0, 0.5), Lambertian((0.3, 0.3, 0.3))))   # also t = 1.5
+    r = oracle.trace_one(s.flatten(), tables, (0, 0, 2.0), (0, 0, -1.0))
+    assert r["index"] == 2 and r["t"] == f32(1.5)
+
+
+def test_closest_wins_regardless_of_order(oracle, tables):
+    s = HittableList()
+    s.add(Sphere((0.0, 0.0, -5.0), 0.5, Lambertian((0.1, 0.1, 0.1))))
+    s.add(Sphere((0.0, 0.0, 0.0), 0.5, Lambertian((0.2, 0.2, 0.2))))
+    s.add(Sphere((0.0, 0.0, -9.0), 0.5, Lambertian((0.3, 0.3, 0.3))))
+    r = oracle.trace_one(s.flatten(), tables, (0, 0, 2.0), (0, 0, -1.0))
+    assert r["index"] == 1 and r["t"] == f32(1.5)
+
+
+# -------------------------------------------------------------- materials
+def test_unit_sphere_lookup_and_lambertian(oracle, tables):
+    """BlueNoise::random_in_unit_sphere src/denoising/mod.rs:37-50: entry
+    (counter+1)%256, times sp_bn(pixel) = screen[128*(i%128) + j%128], times 1.1;
+    Lambertian adds it to the normal (:290)."""
+    flat = one(Plane((0.0, 1.0, 0.0), (0.0, 0.0, 0.0), Lambertian((0.3, 0.3, 0.3))))
+    i, j, tick = 130, 5, 255 + 7          # 130 % 128 = 2; (tick+1) % 256 = 7
+    sp = tables["screen"][128 * 2 + 5]
+    v = tables["sphere"][3 * 7:3 * 7 + 3]
+    want = (v * sp) * f32(1.1)
+    r = oracle.trace_one(flat, tables, (0.0, 2.0, 0.0), (0.0, -1.0, 0.0), pix=(i, j), sphere_tick=tick)
+    got = r["dir"]
+    expect = np.array([0, 1, 0], dtype=f32) + want
+    if expect[0] < 0 and expect[1] < 0 and expect[2] < 0:
+        expect = np.array([0, 1, 0], dtype=f32)
+    assert np.array_equal(got, expect)
+
+
+def test_lambertian_all_negative_direction_falls_back_to_normal(oracle, tables):
+    """vec3::is_near_zero is `x<0 && y<0 && z<0` (src/vector/mod.rs:29-32), so a
+    scatter direction with three negative components is replaced by the normal
+    (src/geometry/mod.rs:292-294)."""
+    # a table whose every entry is (-1,-1,-1)/sqrt(3) and sp_bn = 1: normal (0,-1,0) + ... is all negative
+    t = dict(tables)
+    t["sphere"] = np.full(768, -1.0 / math.sqrt(3.0), dtype=f32)
+    t["screen"] = np.ones(16384, dtype=f32)
+    flat = one(Plane((0.0, 1.0, 0.0), (0.0, 0.0, 0.0), Lambertian((0.3, 0.3, 0.3))))
+    r = oracle.trace_one(flat, t, (0.0, -2.0, 0.0), (0.0, 1.0, 0.0))      # hits from below: normal (0,-1,0)
+    assert np.array_equal(r["normal"], np.array([0, -1, 0], dtype=f32))
+    assert np.array_equal(r["dir"], np.array([0, -1, 0], dtype=f32))
+    up = oracle.trace_one(flat, t, (0.0, 2.0, 0.0), (0.0, -1.0, 0.0))     # normal (0,1,0): y stays positive
+    assert up["dir"][1] > 0 and up["dir"][0] < 0
+
+
+def test_zero_screen_noise_means_pure_mirror(oracle, tables):
+    """sp_bn = 0 scales the perturbation to zero: fuzzy metal reflects exactly"""
+    flat = one(Sphere((0.0, 0.0, 0.0), 0.5, Metal((0.8, 0.6, 0.2), 0.25)))
+    r = oracle.trace_one(flat, zero_screen(tables), (0, 0, 2.0), (0, 0, -1.0))
+    assert np.array_equal(r["dir"], np.array([0, 0, 1], dtype=f32))
+
+
+def test_metal_may_scatter_below_surface(oracle, tables):
+    """no dot(dir, n) > 0 test in Metal::scatter (:275-280): grazing + fuzz can go inward"""
+    t = dict(tables)
+    t["sphere"] = np.tile(np.array([0, -1, 0], dtype=f32), 256)
+    t["screen"] = np.ones(16384, dtype=f32)
+    flat = one(Plane((0.0, 1.0, 0.0), (0.0, 0.0, 0.0), Metal((1, 1, 1), 0.9)))
+    r = oracle.trace_one(flat, t, (0.0, 0.125, 0.0), (1.0, -0.125, 0.0))
+    assert r["hit"] and r["dir"][1] < 0
+
+
+def test_dielectric_normal_incidence(oracle, tables):
+    """Dielectric::scatter :323-346 at normal incidence on a front face:
+    ratio 1/1.5, cos=1, sin=0; reflectance r0 = ((1-r)/(1+r))^2 = 0.04, so the coin
+    refracts 96 % of the time: refract -> perp = (uv + n*1)*ratio = 0, parallel = -n*sqrt|1-0|."""
+    flat = one(Sphere((0.0, 0.0, 0.0), 0.5, Dielectric((1.0, 1.0, 1.0), 1.5)))
+    r = oracle.trace_one(flat, tables, (0, 0, 2.0), (0, 0, -3.0))
+    assert r["hit"] and r["front_face"]
+    assert np.array_equal(np.abs(r["dir"]), np.array([0, 0, 1], dtype=f32))
+    assert np.array_equal(r["attenuation"], np.array([1, 1, 1], dtype=f32))
+
+
+def test_dielectric_total_internal_reflection(oracle, tables):
+    """inside glass (front_face false -> ratio 1.5) at 60 degrees: 1.5*sin > 1 -> reflect, no coin"""
+    flat = one(Plane((0.0, 1.0, 0.0), (0.0, 0.0, 0.0), Dielectric((1, 1, 1), 1.5)))
+    d = (math.sqrt(3.0) / 2.0, 0.5, 0.0)     # travelling upward from below: normal flips to (0,-1,0)
+    r = oracle.trace_one(flat, tables, (0.0, -1.0, 0.0), d)
+    assert r["hit"] and not r["front_face"]
+    ud = np.array(d, dtype=f32)
+    ud = ud / np.sqrt(ud[0] * ud[0] + ud[1] * ud[1] + ud[2] * ud[2])
+    n = np.array([0, -1, 0], dtype=f32)
+    dot = ud[0] * n[0] + ud[1] * n[1] + ud[2] * n[2]
+    want = ud - (n * f32(2.0)) * dot
+    assert np.array_equal(r["dir"], want)
+
+
+# ---------------------------------------------------------------- triangles
+def test_triangle_definition(oracle, tables):
+    tri = Triangle((0.0, 0.0, 0.0), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), Lambertian((0.5, 0.5, 0.5)))
+    flat = one(tri)
+    r = oracle.trace_one(flat, zero_screen(tables), (0.25, 0.25, 1.0), (0.0, 0.0, -1.0))
+    assert r["hit"] and r["t"] == f32(1.0) and r["front_face"]
+    assert np.array_equal(r["normal"], np.array([0, 0, 1], dtype=f32))
+    back = oracle.trace_one(flat, zero_screen(tables), (0.25, 0.25, -1.0), (0.0, 0.0, 1.0))
+    assert back["hit"] and not back["front_face"]
+    assert not oracle.trace_one(flat, tables, (0.75, 0.75, 1.0), (0.0, 0.0, -1.0))["hit"]   # u+v > 1
+    assert not oracle.trace_one(flat, tables, (0.25, 0.25, 1.0), (1.0, 0.0, 0.0))["hit"]    # parallel: det == 0
+
+
+# ------------------------------------------------------------ sky, camera, quantiser
+def test_sky_gradient(oracle):
+    """src/raytracer.rs:81-91: t = 0.5*unit.y + 1.0 (not 0.5*(y+1)); sqrt per channel"""
+    c = oracle.sky((0.0, 3.0, 0.0), gamma=False)     # t = 1.5 -> (1-1.5) + (0.5,0.7,1)*1.5
+    want = np.array([1, 1, 1], dtype=f32) * (f32(1) - f32(1.5)) + np.array([0.5, 0.7, 1.0], dtype=f32) * f32(1.5)
+    assert np.array_equal(c, want)
+    g = oracle.sky((0.0, 3.0, 0.0), gamma=True)
+    assert np.array_equal(g, np.sqrt(want))
+    down = oracle.sky((0.0, -1.0, 0.0), gamma=True)  # t = 0.5 -> (0.75, 0.85, 1.0)
+    assert np.array_equal(down, np.sqrt(np.array([0.75, 0.85, 1.0], dtype=f32)))
+
+
+def test_get_ray_formula(oracle):
+    """Camera::get_ray src/camera/mod.rs:75-79 with numbers exact in binary"""
+    from raytracing_amd import _lib
+    cam = _lib.rt_camera()
+    cam.origin[:] = (1.0, 2.0, 3.0)
+    cam.lower_left_corner[:] = (-2.0, -1.0, -4.0)
+    cam.horizontal[:] = (4.0, 0.0, 0.0)
+    cam.vertical[:] = (0.0, 2.0, 0.0)
+    cam.u[:] = (1.0, 0.0, 0.0)
+    cam.v[:] = (0.0, 1.0, 0.0)
+    cam.lens_radius = 0.5
+    o, d = oracle.get_ray(cam, 0.25, 0.5, 0.5, -1.0)
+    # rd = (0.25,-0.5,0); offset = u*0.25 + v*-0.5 = (0.25,-0.5,0)
+    assert np.array_equal(o, np.array([1.25, 1.5, 3.0], dtype=f32))
+    # llc + hor*0.25 + ver*0.5 - origin - offset = (-2+1-1-0.25, -1+1-2+0.5, -4-3)
+    assert np.array_equal(d, np.array([-2.25, -1.5, -7.0], dtype=f32))
+
+
+def test_scene_camera_matches_anchor_values(oracle):
+    """Camera::new src/camera/mod.rs:35-73 on Scene::get_camera's arguments
+    (src/scene/mod.rs:59-76); anchors computed independently in float64"""
+    cam = oracle.scene_camera(0, 0.0)
+    o = np.array([1.0, 1.3, 4.0]); la = np.array([0.25, 0.6, -0.5])
+    w = (o - la) / np.linalg.norm(o - la)
+    u = np.cross([0, 1, 0], w); u /= np.linalg.norm(u)
+    v = np.cross(w, u)
+    fd = np.linalg.norm(o - la)
+    vh = 2 * math.tan(math.radians(27.0) / 2); vw = vh * 16 / 9
+    assert np.allclose(cam.u[:], u, rtol=0, atol=2e-7)
+    assert np.allclose(cam.v[:], v, rtol=0, atol=2e-7)
+    assert np.allclose(cam.horizontal[:], u * vw * fd, rtol=0, atol=2e-6)
+    assert np.allclose(cam.vertical[:], v * vh * fd, rtol=0, atol=2e-6)
+    assert np.allclose(cam.lower_left_corner[:], o - u * vw * fd / 2 - v * vh * fd / 2 - w * fd, rtol=0, atol=4e-6)
+    assert cam.lens_radius == 0.0
+    assert oracle.scene_camera(0, 0.1).lens_radius == f32(0.1) / f32(2.0)
+    moved = oracle.scene_camera(7, 0.0)             # origin.z = 4.0 - 7*0.1 (:61-63)
+    assert moved.origin[2] == f32(4.0) - f32(7.0) * f32(0.1)
+
+
+def test_image_height_rule(oracle):
+    """src/raytracer.rs:118-120 in f32: 600->337, 1080->607, 1920->1080, 3840->2160"""
+    a = float(f32(16.0) / f32(9.0))
+    assert [oracle.image_height(w, a) for w in (600, 1080, 1920, 3840)] == [337, 607, 1080, 2160]
+
+
+def test_quantiser(oracle):
+    """write_colour src/raytracer.rs:46-55: scale by 1/spp, clamp to [0,0.999],
+    (256*x) as u8 truncates, NaN -> 0, pack 0x00RRGGBB"""
+    acc = np.zeros((1, 6, 4), dtype=f32)
+    acc[0, 0] = (0.5, 1.0, 2.0, 1)          # 128, 255 (0.999*256=255.7), 255
+    acc[0, 1] = (1.0, 2.0, 3.0, 4)          # /4 -> 0.25,0.5,0.75 -> 64,128,192
+    acc[0, 2] = (-1.0, 0.0, 0.00390625, 1)  # 0, 0, 1
+    acc[0, 3] = (np.nan, 0.5, 0.5, 1)       # NaN passes the clamp, `as u8` gives 0
+    acc[0, 4] = (np.inf, -np.inf, 0.998, 1) # 255, 0, 255 (255.488)
+    acc[0, 5] = (0.1, 0.2, 0.3, 1)
+    p = oracle.pack(acc)[0]
+    assert p[0] == (128 << 16) | (255 << 8) | 255
+    assert p[1] == (64 << 16) | (128 << 8) | 192
+    assert p[2] == 1
+    assert p[3] == (0 << 16) | (128 << 8) | 128
+    assert p[4] == (255 << 16) | 255
+    assert p[5] == (int(f32(256) * f32(0.1)) << 16) | (int(f32(256) * f32(0.2)) << 8) | int(f32(256) * f32(0.3))
+
+
+# ---------------------------------------------------------- whole-loop properties
+W0, H0 = 96, 54
+
+
+def _render(oracle, tables, **kw):
+    flat = kw.pop("flat", None) or Scene.get_scene().flatten()
+    cam = kw.pop("cam", None) or oracle.scene_camera(0, kw.pop("aperture", 0.0))
+    mode = kw.pop("mode", oracle_lib.MODE_DET)
+    threads = kw.pop("threads", 4)
+    p = make_params(W0, H0, **kw)
+    return oracle.render(flat, cam, tables, p, mode=mode, threads=threads)
+
+
+def test_first_disc_lookup_uses_entry_one(oracle, tables):
+    """counters pre-increment (src/denoising/mod.rs:13-17): pixel (0,0) sample 0
+    jitters with disc[1] and its lens sample is disc[2].  With an empty list the
+    pixel is pure sky, so its colour reveals the primary direction."""
+    from raytracing_amd import _lib
+    empty = HittableList().flatten()
+    cam = oracle.scene_camera(0, 0.0)
+    p = make_params(W0, H0, spp=1)
+    acc, ids, seg = oracle.render(empty, cam, tables, p, threads=1)
+    ox, oy = tables["disc"][2], tables["disc"][3]
+    u = (f32(0) + ox) / f32(W0 - 1); v = (f32(0) + oy) / f32(H0 - 1)
+    _, d = oracle.get_ray(cam, float(u), float(v), 0.0, 0.0)
+    want = oracle.sky(tuple(float(x) for x in d), gamma=True)
+    assert np.array_equal(acc[H0 - 1, 0, :3], want)      # j=0 is the bottom row (src/raytracer.rs:265)
+    assert seg == W0 * H0 and (ids == -1).all()
+    assert (acc[..., 3] == 1).all()
+
+
+def test_threads_do_not_change_det_results(oracle, tables):
+    a1, i1, s1 = _render(oracle, tables, spp=2, threads=1)
+    a8, i8, s8 = _render(oracle, tables, spp=2, threads=7)
+    assert np.array_equal(a1.view(np.uint32), a8.view(np.uint32)) and np.array_equal(i1, i8) and s1 == s8
+
+
+def test_progressive_equals_one_shot(oracle, tables):
+    flat = Scene.get_scene().flatten(); cam = oracle.scene_camera(0, 0.1)
+    full, ids_full, seg_full = oracle.render(flat, cam, tables, make_params(W0, H0, spp=5))
+    acc = np.zeros((H0, W0, 4), dtype=f32); seg = 0; ids = None
+    for b, c in ((0, 2), (2, 1), (3, 2)):
+        _, i, s = oracle.render(flat, cam, tables, make_params(W0, H0, spp=5, sample_begin=b, sample_count=c),
+                                accum=acc)
+        seg += s
+        if b == 0:
+            ids = i
+    assert np.array_equal(acc.view(np.uint32), full.view(np.uint32)) and seg == seg_full
+    assert np.array_equal(ids, ids_full)
+
+
+def test_band_partition_covers_frame_once(oracle, tables):
+    flat = Scene.get_scene().flatten(); cam = oracle.scene_camera(0, 0.0)
+    full, ids_full, seg_full = oracle.render(flat, cam, tables, make_params(W0, H0, spp=1))
+    acc = np.zeros((H0, W0, 4), dtype=f32); seg = 0
+    for g in range(3):
+        _, _, s = oracle.render(flat, cam, tables, make_params(W0, H0, spp=1, band_begin=g, band_stride=3),
+                                accum=acc, want_ids=False)
+        seg += s
+    assert np.array_equal(acc.view(np.uint32), full.view(np.uint32)) and seg == seg_full
+
+
+def test_depth_budget(oracle, tables):
+    """ray_colour depth counts scene.hit calls (src/raytracer.rs:69,75): with a
+    budget of 1 every pixel that hits anything is black, sky pixels keep colour"""
+    acc, ids, seg = _render(oracle, tables, spp=1, max_bounces=1)
+    assert seg == W0 * H0
+    assert (acc[ids >= 0][:, :3] == 0).all() and (acc[ids < 0][:, :3] > 0).all()
+    acc0, _, seg0 = _render(oracle, tables, spp=1, max_bounces=0)
+    assert seg0 == 0 and (acc0[..., :3] == 0).all()
+    _, _, seg10 = _render(oracle, tables, spp=1, max_bounces=10)
+    assert W0 * H0 < seg10 <= 10 * W0 * H0
+
+
+def test_ref_seq_mode_has_reference_primary_rays(oracle, tables):
+    """the one-thread global-counter order of the reference (REF_SEQ) and the
+    closed-form schedule (DET) generate identical primary rays on the first
+    frame: same primary-hit ids for every pixel"""
+    _, ids_det, _ = _render(oracle, tables, spp=1)
+    _, ids_seq, _ = _render(oracle, tables, spp=1, mode=oracle_lib.MODE_REF_SEQ)
+    assert np.array_equal(ids_det, ids_seq)
+    _, ids_det3, _ = _render(oracle, tables, spp=3, aperture=0.1)
+    _, ids_seq3, _ = _render(oracle, tables, spp=3, aperture=0.1, mode=oracle_lib.MODE_REF_SEQ)
+    assert np.array_equal(ids_det3, ids_seq3)
+
+
+def test_det_and_ref_seq_images_agree_statistically(oracle, tables):
+    """the two schedules differ only in which table entries later bounces draw;
+    at 64 spp the images must agree to PSNR >= 40 dB on [0,1] radiance (RMSE <=
+    2.55/255).  Measured 42.2 dB, the same as between two DET renders with
+    different seeds: the residual is the Monte-Carlo noise of either image."""
+    a, _, _ = _render(oracle, tables, spp=64)
+    b, _, _ = _render(oracle, tables, spp=64, mode=oracle_lib.MODE_REF_SEQ)
+    x = np.clip(a[..., :3] / 64, 0, 1); y = np.clip(b[..., :3] / 64, 0, 1)
+    mse = float(np.mean((x - y) ** 2))
+    psnr = 10 * math.log10(1.0 / mse)
+    assert psnr >= 40.0, psnr
+
+
+def test_default_scene_statistics(oracle, tables):
+    """sanity anchors of the default frame: every list entry except the inner
+    glass shell is seen by some primary ray, the plane dominates"""
+    flat = Scene.get_scene().flatten(); cam = oracle.scene_camera(0, 0.0)
+    h = image_height(600)
+    acc, ids, seg = oracle.render(flat, cam, tables, make_params(600, h, spp=1), threads=8)
+    counts = np.bincount(ids.ravel() + 1, minlength=9)
+    assert counts.sum() == 600 * 337 and counts[0] > 0
+    assert counts[8] == counts.max()            # plane (id 7)
+    assert counts[6] == 0                       # id 5: negative-radius shell is never the primary hit
+    assert all(counts[k + 1] > 0 for k in (0, 1, 2, 3, 4, 6))
