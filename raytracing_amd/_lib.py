@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+# RT_HIP_LIBRARY overrides the path (e.g. to A/B two builds of the kernels)
+LIB_PATH = os.environ.get("RT_HIP_LIBRARY") or os.path.join(_HERE, "librt_hip.so")
 
 RT_OK, RT_E_BADARG, RT_E_HIP, RT_E_OOM, RT_E_STATE, RT_E_IO = 0, -1, -2, -3, -4, -5
 RT_METAL, RT_LAMBERTIAN, RT_DIELECTRIC = 0, 1, 2

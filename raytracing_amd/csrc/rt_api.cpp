@@ -90,6 +90,23 @@ inline float bits_to_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return
 
 struct ListEntry { int kind = -1; uint32_t k = 0; };
 
+// Threshold of the kernel's conservative sphere rejection test (see cull_pass):
+//   thr = r^2 (1+eps) - |c|^2 (1-eps),  eps = 2^-16,
+// evaluated in double and rounded UP to float so rounding can only make the
+// test reject less.  Spheres whose magnitudes would leave the range where the
+// kernel's error bound holds (squares near overflow or underflow) get +inf:
+// never rejected, always handed to the exact test.
+float cull_threshold(float cx, float cy, float cz, float r) {
+    const double eps = 1.0 / 65536.0;
+    const double c2 = (double)cx * cx + (double)cy * cy + (double)cz * cz;
+    const double r2 = (double)r * r;
+    if (!(c2 < 1e30) || !(r2 < 1e30) || !(c2 + r2 > 1e-24)) return INFINITY;
+    const double thr = r2 * (1.0 + eps) - c2 * (1.0 - eps);
+    float f = (float)thr;
+    if ((double)f < thr) f = std::nextafterf(f, INFINITY);
+    return f;
+}
+
 // number of 8-row bands b < ceil(H/8) with b % stride == begin
 uint32_t bands_of(uint32_t height, uint32_t begin, uint32_t stride) {
     const uint32_t total = (height + RT_BAND_ROWS - 1u) / RT_BAND_ROWS;
@@ -210,7 +227,7 @@ int rt_upload_scene(rt_ctx *ctx, const rt_scene *s) {
             while (sph_geom.size() % DEV_SPHERE_BATCH) {
                 // a sphere no ray can reach: the conservative test always rejects it
                 sph_geom.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
-                sph_cull.push_back(make_float4(0.f, 0.f, 0.f, -INFINITY));
+                sph_cull.push_back(make_float4(0.f, 0.f, 0.f, -INFINITY));   // g > -inf: always rejected
                 sph_mat.push_back(0);
             }
         };
@@ -230,7 +247,7 @@ int rt_upload_scene(rt_ctx *ctx, const rt_scene *s) {
             if (kind == DEV_SPHERE) {
                 const float cx = s->sph_cx[k], cy = s->sph_cy[k], cz = s->sph_cz[k], r = s->sph_r[k];
                 sph_geom.push_back(make_float4(cx, cy, cz, r));
-                sph_cull.push_back(make_float4(cx, cy, cz, 0.0f));
+                sph_cull.push_back(make_float4(cx, cy, cz, cull_threshold(cx, cy, cz, r)));
                 sph_mat.push_back(s->sph_mat[k]);
             } else if (kind == DEV_PLANE) {
                 planes.push_back(make_float4(s->pl_nx[k], s->pl_ny[k], s->pl_nz[k], bits_to_float(s->pl_mat[k])));

@@ -13,7 +13,9 @@ enum { DEV_SPHERE = 0, DEV_PLANE = 1, DEV_CUBE = 2, DEV_TRI = 3 };
 
 // spheres of one run are padded to a multiple of this many entries with
 // spheres that can never be hit, so the scan can take them in fixed batches
-#define DEV_SPHERE_BATCH 4u
+#define DEV_SPHERE_BATCH 8u
+// sphere runs at least this long go through the conservative rejection test
+#define DEV_CULL_MIN_RUN 32u
 
 // The primitive list in device memory.  The reference's insertion-ordered
 // Vec<Box<dyn Hittable>> (src/geometry/mod.rs:228-238) is cut into maximal

@@ -70,6 +70,7 @@ constexpr uint32_t GOLDEN32 = 0x9E3779B9u;
 // are never written while a render kernel runs.
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+typedef float f16 __attribute__((ext_vector_type(16)));
 #define RT_CONST_AS __attribute__((address_space(4)))
 template <typename T, typename S>
 __device__ __forceinline__ const RT_CONST_AS T *const_ptr(const S *p) {
@@ -143,13 +144,75 @@ struct Hit {
     bool ff;        // front_face as the shared temp record held it at accept time
 };
 
+// Sphere::hit, src/geometry/mod.rs:60-94, up to the point where the hit is
+// accepted; h.t plays closest_so_far.  `a` is |dir|^2 (:63).
+__device__ __forceinline__ void sphere_exact(const SceneView &sc, uint32_t slot, int32_t id, const Ray &ray,
+                                             float a, float t_min, Hit &h, bool &ff_shared) {
+    const f4 g = sc.sph_geom[slot];   // cx, cy, cz, radius
+    V3 oc = ray.o - mk(g.x, g.y, g.z);
+    float half_b = dot(oc, ray.d);
+    float c = len2(oc) - g.w * g.w;
+    float disc = half_b * half_b - a * c;
+    if (disc < 0.0f) return;
+    float d_sqrt = __builtin_sqrtf(disc);
+    float root = -(half_b + d_sqrt) / a;
+    if (root < t_min || h.t < root) {
+        root = (-half_b + d_sqrt) / a;
+        if (root < t_min || h.t < root) return;
+    }
+    h.t = root; h.kind = DEV_SPHERE; h.slot = slot; h.id = id;
+    if (sc.need_ff_shared) {
+        V3 p = ray.o + ray.d * root;
+        V3 outward = (p - mk(g.x, g.y, g.z)) / g.w;
+        ff_shared = dot(ray.d, outward) < 0.0f;
+    }
+}
+
+// ----------------------------------------------------------------------
+// Conservative sphere rejection.  With u the unit direction, the squared
+// distance from a centre c to the ray's line is |c-o|^2 - ((c-o).u)^2; the
+// sphere cannot be hit when that exceeds r^2.  Expanded so that no per-sphere
+// subtraction is needed:
+//     g = |o|^2 (1-eps) - 2 o.c - ((c.u) - (o.u))^2        (7 fused ops)
+//     reject  <=>  g > r^2 (1+eps) - |c|^2 (1-eps) = thr   (1 compare)
+// i.e. dist^2 - r^2 > eps (|o|^2 + |c|^2 + r^2).  Sphere::hit misses (its
+// discriminant, evaluated in f32 without fusing, is negative) whenever
+// dist^2 - r^2 > 19.5 ulp |o-c|^2; the rounding of the seven fused ops, of
+// u, o.u and thr adds at most 30 ulp (|o|+|c|)^2, and (|o|+|c|)^2 <=
+// 2(|o|^2+|c|^2), so eps = 2^-16 = 256 ulp covers both with a factor 2.6 to
+// spare.  The test never ACCEPTS anything: survivors run Sphere::hit itself.
+// NaN or infinite intermediates compare false and survive.
+// ----------------------------------------------------------------------
+struct Cull { float ux, uy, uz, nou, ax, ay, az, oo; };
+constexpr float CULL_EPS = 1.0f / 65536.0f;
+
+__device__ __forceinline__ Cull cull_setup(const Ray &ray, float a, bool tracing) {
+    Cull c;
+    const float len = __builtin_sqrtf(a);
+    c.ux = ray.d.x / len; c.uy = ray.d.y / len; c.uz = ray.d.z / len;
+    c.nou = -__builtin_fmaf(ray.o.x, c.ux, __builtin_fmaf(ray.o.y, c.uy, ray.o.z * c.uz));
+    c.ax = -2.0f * ray.o.x; c.ay = -2.0f * ray.o.y; c.az = -2.0f * ray.o.z;
+    const float oo = __builtin_fmaf(ray.o.x, ray.o.x, __builtin_fmaf(ray.o.y, ray.o.y, ray.o.z * ray.o.z));
+    // lanes with no ray to trace reject everything
+    c.oo = tracing ? oo * (1.0f - CULL_EPS) : __builtin_inff();
+    return c;
+}
+// record {cx, cy, cz, thr}; true = the sphere may be hit, run the exact test
+__device__ __forceinline__ bool cull_pass(const Cull &c, float cx, float cy, float cz, float thr) {
+    const float m = __builtin_fmaf(cx, c.ux, __builtin_fmaf(cy, c.uy, __builtin_fmaf(cz, c.uz, c.nou)));
+    const float w = __builtin_fmaf(cx, c.ax, __builtin_fmaf(cy, c.ay, __builtin_fmaf(cz, c.az, c.oo)));
+    const float g = __builtin_fmaf(-m, m, w);
+    return !(g > thr);
+}
+
 // ----------------------------------------------------------------------
 // HittableList::hit, src/geometry/mod.rs:240-258, without the scatter calls:
 // scatter results of hits that do not end up closest are discarded by the
 // reference, so only (t, primitive, front_face) is tracked here and the record
 // of the final hit is rebuilt afterwards from the same inputs.
 // ----------------------------------------------------------------------
-__device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, float t_min, Hit &h) {
+__device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, float t_min, bool tracing,
+                                          Hit &h) {
     h.t = __builtin_inff();
     h.kind = -1;
     h.slot = 0;
@@ -157,28 +220,53 @@ __device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, f
     h.ff = true;
     bool ff_shared = true;   // temp_hr.front_face, default true (src/geometry/mod.rs:36-39,241)
     const float a = len2(ray.d);   // Sphere::hit :63, the same for every sphere
+    Cull cull;
+    bool have_cull = false;
     for (uint32_t r = 0; r < sc.n_runs; ++r) {
         const u4 run = sc.runs[r];   // {kind, first, count, id0}
         if (run.x == DEV_SPHERE) {
-            // Sphere::hit, src/geometry/mod.rs:60-94
-            for (uint32_t k = 0; k < run.z; ++k) {
-                const f4 g = sc.sph_geom[run.y + k];   // cx, cy, cz, radius
-                V3 oc = ray.o - mk(g.x, g.y, g.z);
-                float half_b = dot(oc, ray.d);
-                float c = len2(oc) - g.w * g.w;
-                float disc = half_b * half_b - a * c;
-                if (disc < 0.0f) continue;
-                float d_sqrt = __builtin_sqrtf(disc);
-                float root = -(half_b + d_sqrt) / a;
-                if (root < t_min || h.t < root) {
-                    root = (-half_b + d_sqrt) / a;
-                    if (root < t_min || h.t < root) continue;
-                }
-                h.t = root; h.kind = DEV_SPHERE; h.slot = run.y + k; h.id = (int32_t)(run.w + k);
-                if (sc.need_ff_shared) {
-                    V3 p = ray.o + ray.d * root;
-                    V3 outward = (p - mk(g.x, g.y, g.z)) / g.w;
-                    ff_shared = dot(ray.d, outward) < 0.0f;
+            if (run.z < DEV_CULL_MIN_RUN) {
+                for (uint32_t k = 0; k < run.z; ++k)
+                    sphere_exact(sc, run.y + k, (int32_t)(run.w + k), ray, a, t_min, h, ff_shared);
+            } else {
+                // Long runs: eight spheres per step through the conservative rejection
+                // test (8 VALU instructions each); only spheres some lane cannot
+                // reject reach Sphere::hit proper, in list order.  The run is padded
+                // to a multiple of eight with entries the test always rejects.
+                if (!have_cull) { cull = cull_setup(ray, a, tracing); have_cull = true; }
+                const uint32_t n8 = (run.z + DEV_SPHERE_BATCH - 1u) / DEV_SPHERE_BATCH;
+                const RT_CONST_AS f16 *rec = (const RT_CONST_AS f16 *)(sc.sph_cull + run.y);
+                for (uint32_t b = 0; b < n8; ++b) {
+                    // two s_load_dwordx16: eight {cx,cy,cz,thr} records into SGPRs
+                    const f16 ra = rec[2 * b], rb = rec[2 * b + 1];
+                    const bool p0 = cull_pass(cull, ra.s0, ra.s1, ra.s2, ra.s3);
+                    const bool p1 = cull_pass(cull, ra.s4, ra.s5, ra.s6, ra.s7);
+                    const bool p2 = cull_pass(cull, ra.s8, ra.s9, ra.sa, ra.sb);
+                    const bool p3 = cull_pass(cull, ra.sc, ra.sd, ra.se, ra.sf);
+                    const bool p4 = cull_pass(cull, rb.s0, rb.s1, rb.s2, rb.s3);
+                    const bool p5 = cull_pass(cull, rb.s4, rb.s5, rb.s6, rb.s7);
+                    const bool p6 = cull_pass(cull, rb.s8, rb.s9, rb.sa, rb.sb);
+                    const bool p7 = cull_pass(cull, rb.sc, rb.sd, rb.se, rb.sf);
+                    // wave-level "does any lane need the exact test": the compare masks
+                    // already are SGPR pairs, so this is a chain of s_or_b64 and one
+                    // scalar branch
+                    const unsigned long long any =
+                        __builtin_amdgcn_ballot_w64(p0) | __builtin_amdgcn_ballot_w64(p1) |
+                        __builtin_amdgcn_ballot_w64(p2) | __builtin_amdgcn_ballot_w64(p3) |
+                        __builtin_amdgcn_ballot_w64(p4) | __builtin_amdgcn_ballot_w64(p5) |
+                        __builtin_amdgcn_ballot_w64(p6) | __builtin_amdgcn_ballot_w64(p7);
+                    if (any != 0ull) {
+                        const uint32_t s0 = run.y + b * DEV_SPHERE_BATCH;
+                        const int32_t id0 = (int32_t)(run.w + b * DEV_SPHERE_BATCH);
+                        if (p0) sphere_exact(sc, s0, id0, ray, a, t_min, h, ff_shared);
+                        if (p1) sphere_exact(sc, s0 + 1, id0 + 1, ray, a, t_min, h, ff_shared);
+                        if (p2) sphere_exact(sc, s0 + 2, id0 + 2, ray, a, t_min, h, ff_shared);
+                        if (p3) sphere_exact(sc, s0 + 3, id0 + 3, ray, a, t_min, h, ff_shared);
+                        if (p4) sphere_exact(sc, s0 + 4, id0 + 4, ray, a, t_min, h, ff_shared);
+                        if (p5) sphere_exact(sc, s0 + 5, id0 + 5, ray, a, t_min, h, ff_shared);
+                        if (p6) sphere_exact(sc, s0 + 6, id0 + 6, ray, a, t_min, h, ff_shared);
+                        if (p7) sphere_exact(sc, s0 + 7, id0 + 7, ray, a, t_min, h, ff_shared);
+                    }
                 }
             }
         } else if (run.x == DEV_PLANE) {
@@ -405,7 +493,7 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
 
     while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
         Hit h;
-        scan_list(sc, ray, p.t_min, h);
+        scan_list(sc, ray, p.t_min, alive, h);
         n_seg += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(alive));
         if (alive) {
             if (s == 0u && n_stack == 0u) fr.primary_ids[pix_out] = h.id;
