@@ -139,8 +139,8 @@ int rt_create(int device, rt_ctx **out) {
     if ((e = hipMalloc(reinterpret_cast<void **>(&c->d_disc), 128 * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc(reinterpret_cast<void **>(&c->d_sphere), 768 * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc(reinterpret_cast<void **>(&c->d_screen), 16384 * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc");
-    if ((e = hipMalloc(reinterpret_cast<void **>(&c->d_segments), sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
-    if ((e = hipMemset(c->d_segments, 0, sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset");
+    if ((e = hipMalloc(reinterpret_cast<void **>(&c->d_segments), 8 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMemset(c->d_segments, 0, 8 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset");
     *out = reinterpret_cast<rt_ctx *>(c);
     return RT_OK;
 }
@@ -279,6 +279,15 @@ int rt_upload_scene(rt_ctx *ctx, const rt_scene *s) {
         return fail(c, RT_E_OOM, "rt_upload_scene: out of host memory");
     }
 
+    // The kernel reads the rejection records two spheres at a time:
+    // {cx0,cx1, cy0,cy1, cz0,cz1, thr0,thr1}.  Runs start at even slots
+    // (padded to multiples of DEV_SPHERE_BATCH), so pairs never straddle runs.
+    for (size_t k = 0; k + 1 < sph_cull.size(); k += 2) {
+        const float4 a = sph_cull[k], b = sph_cull[k + 1];
+        sph_cull[k] = make_float4(a.x, b.x, a.y, b.y);
+        sph_cull[k + 1] = make_float4(a.z, b.z, a.w, b.w);
+    }
+
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // no render may still read the old scene
     free_scene(c);
@@ -330,7 +339,7 @@ int rt_begin_frame(rt_ctx *ctx, uint32_t width, uint32_t height) {
     HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, n_px * sizeof(float4), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_packed, 0, n_px * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_ids, 0xff, n_px * sizeof(int32_t), c->stream));   // -1 = nothing recorded
-    HIP_TRY(c, hipMemsetAsync(c->d_segments, 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_segments, 0, 8 * sizeof(unsigned long long), c->stream));
     return RT_OK;
 }
 
@@ -434,6 +443,19 @@ int rt_ray_count(rt_ctx *ctx, uint64_t *segments) {
     int rc = read_back(c, &v, c->d_segments, sizeof v);
     if (rc != RT_OK) return rc;
     *segments = v;
+    return RT_OK;
+}
+
+// Instrumentation counters of kernels built with -DRTK_STATS (slot 0 is the
+// segment count; the others stay zero in the shipped build).  Development aid,
+// deliberately not part of rt_hip.h.
+int rtdbg_read_counters(rt_ctx *ctx, uint64_t out[8]) {
+    Ctx *c = C(ctx);
+    if (!c || !out) return RT_E_BADARG;
+    unsigned long long v[8] = {0};
+    int rc = read_back(c, v, c->d_segments, sizeof v);
+    if (rc != RT_OK) return rc;
+    for (int k = 0; k < 8; ++k) out[k] = v[k];
     return RT_OK;
 }
 

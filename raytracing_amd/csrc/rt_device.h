@@ -13,7 +13,7 @@ enum { DEV_SPHERE = 0, DEV_PLANE = 1, DEV_CUBE = 2, DEV_TRI = 3 };
 
 // spheres of one run are padded to a multiple of this many entries with
 // spheres that can never be hit, so the scan can take them in fixed batches
-#define DEV_SPHERE_BATCH 8u
+#define DEV_SPHERE_BATCH 16u
 // sphere runs at least this long go through the conservative rejection test
 #define DEV_CULL_MIN_RUN 32u
 
@@ -27,7 +27,8 @@ struct DevScene {
     uint32_t need_ff_shared;  // some Cube has a Dielectric material: its front_face
                               // is inherited from the previously accepted hit
     const float4 *sph_geom;   // cx, cy, cz, radius
-    const float4 *sph_cull;   // cx, cy, cz, reject threshold of the conservative test
+    const float4 *sph_cull;   // conservative-test records, two spheres per 8 floats:
+                              // {cx0,cx1, cy0,cy1, cz0,cz1, thr0,thr1}
     const uint32_t *sph_mat;
     const float4 *planes;     // 2 per plane: {n, material bits}, {point, 0}
     const float4 *cubes;      // 4 per cube: {center, material bits}, {w/2,h/2,d/2,0}, {corner0,0}, {corner1,0}

@@ -71,6 +71,7 @@ constexpr uint32_t GOLDEN32 = 0x9E3779B9u;
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 typedef float f16 __attribute__((ext_vector_type(16)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 #define RT_CONST_AS __attribute__((address_space(4)))
 template <typename T, typename S>
 __device__ __forceinline__ const RT_CONST_AS T *const_ptr(const S *p) {
@@ -82,9 +83,11 @@ struct SceneView {
     const RT_CONST_AS uint32_t *sph_mat;
     const RT_CONST_AS int32_t *mat_kind;
     uint32_t n_runs, need_ff_shared;
+    unsigned long long *stats;   // fr.segments; slots 1..7 are instrumentation (RTK_STATS builds)
 };
-__device__ __forceinline__ SceneView view_of(const DevScene &sc) {
+__device__ __forceinline__ SceneView view_of(const DevScene &sc, unsigned long long *stats) {
     SceneView v;
+    v.stats = stats;
     v.runs = const_ptr<u4>(sc.runs);
     v.sph_geom = const_ptr<f4>(sc.sph_geom);
     v.sph_cull = const_ptr<f4>(sc.sph_cull);
@@ -136,6 +139,19 @@ __device__ __forceinline__ V3 rius(const Lds &lds, uint32_t seed, float sp_bn) {
 // f32::powi(5) as LLVM expands it
 __device__ __forceinline__ float powi5(float x) { float x2 = x * x; float x4 = x2 * x2; return x * x4; }
 
+// Optional instrumentation (build with -DRTK_STATS): wave-level event counts in
+// fr.segments[1..7].  Not compiled into the shipped library.
+#ifdef RTK_STATS
+#define RTK_COUNT(sc, slot, n)                                                              \
+    do {                                                                                    \
+        unsigned long long n_ = (unsigned long long)(n);                                    \
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u)       \
+            atomicAdd((sc).stats + (slot), n_);                                             \
+    } while (0)
+#else
+#define RTK_COUNT(sc, slot, n) do { } while (0)
+#endif
+
 struct Hit {
     float t;        // closest_so_far, src/geometry/mod.rs:242
     int kind;       // -1 = nothing hit
@@ -173,7 +189,8 @@ __device__ __forceinline__ void sphere_exact(const SceneView &sc, uint32_t slot,
 // distance from a centre c to the ray's line is |c-o|^2 - ((c-o).u)^2; the
 // sphere cannot be hit when that exceeds r^2.  Expanded so that no per-sphere
 // subtraction is needed:
-//     g = |o|^2 (1-eps) - 2 o.c - ((c.u) - (o.u))^2        (7 fused ops)
+//     g = |o|^2 (1-eps) - 2 o.c - ((c.u) - (o.u))^2        (7 fused ops, packed two
+//                                                            spheres per v_pk_fma_f32)
 //     reject  <=>  g > r^2 (1+eps) - |c|^2 (1-eps) = thr   (1 compare)
 // i.e. dist^2 - r^2 > eps (|o|^2 + |c|^2 + r^2).  Sphere::hit misses (its
 // discriminant, evaluated in f32 without fusing, is negative) whenever
@@ -197,12 +214,55 @@ __device__ __forceinline__ Cull cull_setup(const Ray &ray, float a, bool tracing
     c.oo = tracing ? oo * (1.0f - CULL_EPS) : __builtin_inff();
     return c;
 }
-// record {cx, cy, cz, thr}; true = the sphere may be hit, run the exact test
-__device__ __forceinline__ bool cull_pass(const Cull &c, float cx, float cy, float cz, float thr) {
-    const float m = __builtin_fmaf(cx, c.ux, __builtin_fmaf(cy, c.uy, __builtin_fmaf(cz, c.uz, c.nou)));
-    const float w = __builtin_fmaf(cx, c.ax, __builtin_fmaf(cy, c.ay, __builtin_fmaf(cz, c.az, c.oo)));
-    const float g = __builtin_fmaf(-m, m, w);
-    return !(g > thr);
+// g of two spheres at once: seven v_pk_fma_f32, each taking one SGPR pair
+// (the same coordinate of both spheres) and ray values broadcast from one VGPR.
+// A sphere may be hit, and goes to the exact test, unless g > thr.
+__device__ __forceinline__ f2 cull_pair(const Cull &c, f2 cx, f2 cy, f2 cz) {
+    const f2 ux = {c.ux, c.ux}, uy = {c.uy, c.uy}, uz = {c.uz, c.uz}, nou = {c.nou, c.nou};
+    const f2 ax = {c.ax, c.ax}, ay = {c.ay, c.ay}, az = {c.az, c.az}, oo = {c.oo, c.oo};
+    const f2 m = __builtin_elementwise_fma(cx, ux, __builtin_elementwise_fma(cy, uy, __builtin_elementwise_fma(cz, uz, nou)));
+    const f2 w = __builtin_elementwise_fma(cx, ax, __builtin_elementwise_fma(cy, ay, __builtin_elementwise_fma(cz, az, oo)));
+    return __builtin_elementwise_fma(-m, m, w);
+}
+
+// One step of the long-run sphere scan: eight spheres, given as four pair
+// records {cx0,cx1, cy0,cy1, cz0,cz1, thr0,thr1} in ra and rb (SGPRs), starting at
+// position `first` of the run.
+__device__ __forceinline__ void cull_step(const SceneView &sc, const Cull &cull, const f16 ra, const f16 rb,
+                                          const u4 run, uint32_t first, const Ray &ray, float a, float t_min,
+                                          Hit &h, bool &ff_shared) {
+    const f2 g01 = cull_pair(cull, ra.s01, ra.s23, ra.s45);
+    const f2 g23 = cull_pair(cull, ra.s89, ra.sab, ra.scd);
+    const f2 g45 = cull_pair(cull, rb.s01, rb.s23, rb.s45);
+    const f2 g67 = cull_pair(cull, rb.s89, rb.sab, rb.scd);
+    const bool p0 = !(g01.x > ra.s6), p1 = !(g01.y > ra.s7);
+    const bool p2 = !(g23.x > ra.se), p3 = !(g23.y > ra.sf);
+    const bool p4 = !(g45.x > rb.s6), p5 = !(g45.y > rb.s7);
+    const bool p6 = !(g67.x > rb.se), p7 = !(g67.y > rb.sf);
+    // wave-level "does any lane need the exact test": the compare masks already are
+    // SGPR pairs, so this is a chain of s_or_b64 and one scalar branch
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(p0), m1 = __builtin_amdgcn_ballot_w64(p1);
+    const unsigned long long m2 = __builtin_amdgcn_ballot_w64(p2), m3 = __builtin_amdgcn_ballot_w64(p3);
+    const unsigned long long m4 = __builtin_amdgcn_ballot_w64(p4), m5 = __builtin_amdgcn_ballot_w64(p5);
+    const unsigned long long m6 = __builtin_amdgcn_ballot_w64(p6), m7 = __builtin_amdgcn_ballot_w64(p7);
+    RTK_COUNT(sc, 2, 1);
+    if ((m0 | m1 | m2 | m3 | m4 | m5 | m6 | m7) == 0ull) return;
+    // rare (a few percent of the steps): one shared copy of the exact test, run for
+    // the spheres some lane could not reject, in list order
+    RTK_COUNT(sc, 3, 1);
+    const uint32_t lane_bits = (p0 ? 1u : 0u) | (p1 ? 2u : 0u) | (p2 ? 4u : 0u) | (p3 ? 8u : 0u) |
+                               (p4 ? 16u : 0u) | (p5 ? 32u : 0u) | (p6 ? 64u : 0u) | (p7 ? 128u : 0u);
+    const uint32_t any_bits = (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u) | (m3 ? 8u : 0u) |
+                              (m4 ? 16u : 0u) | (m5 ? 32u : 0u) | (m6 ? 64u : 0u) | (m7 ? 128u : 0u);
+    if (first >= run.z) return;                 // a step of padding only
+    const uint32_t left = run.z - first;        // real spheres from here on
+#pragma unroll 1
+    for (uint32_t k = 0; k < 8u; ++k) {
+        if (((any_bits >> k) & 1u) == 0u || k >= left) continue;
+        RTK_COUNT(sc, 4, 1);
+        if ((lane_bits >> k) & 1u)
+            sphere_exact(sc, run.y + first + k, (int32_t)(run.w + first + k), ray, a, t_min, h, ff_shared);
+    }
 }
 
 // ----------------------------------------------------------------------
@@ -222,6 +282,7 @@ __device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, f
     const float a = len2(ray.d);   // Sphere::hit :63, the same for every sphere
     Cull cull;
     bool have_cull = false;
+    RTK_COUNT(sc, 1, 1);
     for (uint32_t r = 0; r < sc.n_runs; ++r) {
         const u4 run = sc.runs[r];   // {kind, first, count, id0}
         if (run.x == DEV_SPHERE) {
@@ -230,43 +291,31 @@ __device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, f
                     sphere_exact(sc, run.y + k, (int32_t)(run.w + k), ray, a, t_min, h, ff_shared);
             } else {
                 // Long runs: eight spheres per step through the conservative rejection
-                // test (8 VALU instructions each); only spheres some lane cannot
-                // reject reach Sphere::hit proper, in list order.  The run is padded
-                // to a multiple of eight with entries the test always rejects.
+                // test; only spheres some lane cannot reject reach Sphere::hit proper,
+                // in list order.  The run is padded to a multiple of sixteen with
+                // entries the test always rejects.
                 if (!have_cull) { cull = cull_setup(ray, a, tracing); have_cull = true; }
-                const uint32_t n8 = (run.z + DEV_SPHERE_BATCH - 1u) / DEV_SPHERE_BATCH;
+                // Two steps of eight spheres per trip, in ping-pong register sets: the
+                // records of the next step are requested BEFORE the current step is
+                // computed, so the scalar-cache / L2 latency of the s_load_dwordx16 pair
+                // overlaps the arithmetic.  Scalar loads return out of order, the only
+                // wait is "all of them"; it is placed right before the next request, when
+                // the awaited data has had a whole step to arrive.
+                const uint32_t n16 = (run.z + DEV_SPHERE_BATCH - 1u) / DEV_SPHERE_BATCH;
                 const RT_CONST_AS f16 *rec = (const RT_CONST_AS f16 *)(sc.sph_cull + run.y);
-                for (uint32_t b = 0; b < n8; ++b) {
-                    // two s_load_dwordx16: eight {cx,cy,cz,thr} records into SGPRs
-                    const f16 ra = rec[2 * b], rb = rec[2 * b + 1];
-                    const bool p0 = cull_pass(cull, ra.s0, ra.s1, ra.s2, ra.s3);
-                    const bool p1 = cull_pass(cull, ra.s4, ra.s5, ra.s6, ra.s7);
-                    const bool p2 = cull_pass(cull, ra.s8, ra.s9, ra.sa, ra.sb);
-                    const bool p3 = cull_pass(cull, ra.sc, ra.sd, ra.se, ra.sf);
-                    const bool p4 = cull_pass(cull, rb.s0, rb.s1, rb.s2, rb.s3);
-                    const bool p5 = cull_pass(cull, rb.s4, rb.s5, rb.s6, rb.s7);
-                    const bool p6 = cull_pass(cull, rb.s8, rb.s9, rb.sa, rb.sb);
-                    const bool p7 = cull_pass(cull, rb.sc, rb.sd, rb.se, rb.sf);
-                    // wave-level "does any lane need the exact test": the compare masks
-                    // already are SGPR pairs, so this is a chain of s_or_b64 and one
-                    // scalar branch
-                    const unsigned long long any =
-                        __builtin_amdgcn_ballot_w64(p0) | __builtin_amdgcn_ballot_w64(p1) |
-                        __builtin_amdgcn_ballot_w64(p2) | __builtin_amdgcn_ballot_w64(p3) |
-                        __builtin_amdgcn_ballot_w64(p4) | __builtin_amdgcn_ballot_w64(p5) |
-                        __builtin_amdgcn_ballot_w64(p6) | __builtin_amdgcn_ballot_w64(p7);
-                    if (any != 0ull) {
-                        const uint32_t s0 = run.y + b * DEV_SPHERE_BATCH;
-                        const int32_t id0 = (int32_t)(run.w + b * DEV_SPHERE_BATCH);
-                        if (p0) sphere_exact(sc, s0, id0, ray, a, t_min, h, ff_shared);
-                        if (p1) sphere_exact(sc, s0 + 1, id0 + 1, ray, a, t_min, h, ff_shared);
-                        if (p2) sphere_exact(sc, s0 + 2, id0 + 2, ray, a, t_min, h, ff_shared);
-                        if (p3) sphere_exact(sc, s0 + 3, id0 + 3, ray, a, t_min, h, ff_shared);
-                        if (p4) sphere_exact(sc, s0 + 4, id0 + 4, ray, a, t_min, h, ff_shared);
-                        if (p5) sphere_exact(sc, s0 + 5, id0 + 5, ray, a, t_min, h, ff_shared);
-                        if (p6) sphere_exact(sc, s0 + 6, id0 + 6, ray, a, t_min, h, ff_shared);
-                        if (p7) sphere_exact(sc, s0 + 7, id0 + 7, ray, a, t_min, h, ff_shared);
-                    }
+                f16 a0 = rec[0], a1 = rec[1];
+                for (uint32_t b = 0; b < n16; ++b) {
+                    asm volatile("; records of the even step have arrived" ::"s"(a0.s0), "s"(a1.s0));
+                    __builtin_amdgcn_sched_barrier(0);
+                    const f16 b0 = rec[4 * b + 2], b1 = rec[4 * b + 3];
+                    __builtin_amdgcn_sched_barrier(0);
+                    cull_step(sc, cull, a0, a1, run, b * DEV_SPHERE_BATCH, ray, a, t_min, h, ff_shared);
+                    asm volatile("; records of the odd step have arrived" ::"s"(b0.s0), "s"(b1.s0));
+                    __builtin_amdgcn_sched_barrier(0);
+                    const uint32_t nb = (b + 1u < n16) ? b + 1u : b;   // the last trip re-reads itself
+                    a0 = rec[4 * nb]; a1 = rec[4 * nb + 1];
+                    __builtin_amdgcn_sched_barrier(0);
+                    cull_step(sc, cull, b0, b1, run, b * DEV_SPHERE_BATCH + 8u, ray, a, t_min, h, ff_shared);
                 }
             }
         } else if (run.x == DEV_PLANE) {
@@ -438,7 +487,7 @@ __device__ __forceinline__ V3 sky(V3 d, bool gamma) {
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64)
 void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
     __shared__ Lds lds;
-    const SceneView sc = view_of(dsc);
+    const SceneView sc = view_of(dsc, fr.segments);
     for (uint32_t k = threadIdx.x; k < 128; k += blockDim.x) lds.disc[k] = fr.tbl_disc[k];
     for (uint32_t k = threadIdx.x; k < 768; k += blockDim.x) lds.sphere[k] = fr.tbl_sphere[k];
     __syncthreads();

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Generates tools/ub_issue2.hip: issue-cost microbenchmarks for mixes of gfx950 VALU
+instructions.  Each variant is a list of 8 instruction templates; {d} = k-th destination
+VGPR, {dp} = k-th destination VGPR pair, {a},{b} VGPRs, {ap},{bp} VGPR pairs, {s} SGPR, {sp} SGPR pair."""
+V = {
+ "mul vgpr": ["v_mul_f32_e32 {d}, {a}, {b}"] * 8,
+ "add vgpr": ["v_add_f32_e32 {d}, {a}, {b}"] * 8,
+ "sub vgpr": ["v_sub_f32_e32 {d}, {a}, {b}"] * 8,
+ "max vgpr": ["v_max_f32_e32 {d}, {a}, {b}"] * 8,
+ "mov vgpr": ["v_mov_b32_e32 {d}, {a}"] * 8,
+ "and vgpr": ["v_and_b32_e32 {d}, {a}, {b}"] * 8,
+ "mul sgpr src0": ["v_mul_f32_e32 {d}, {s}, {b}"] * 8,
+ "mul inline-const src0": ["v_mul_f32_e32 {d}, 2.0, {b}"] * 8,
+ "fma vgpr": ["v_fma_f32 {d}, {a}, {b}, {b}"] * 8,
+ "fmac vgpr": ["v_fmac_f32_e32 {d}, {a}, {b}"] * 8,
+ "pk_fma vgpr": ["v_pk_fma_f32 {dp}, {ap}, {bp}, {bp}"] * 8,
+ "pk_fma sgpr-pair src0": ["v_pk_fma_f32 {dp}, {sp}, {bp}, {bp}"] * 8,
+ "pk_fma sgpr-pair src0, bcast src1": ["v_pk_fma_f32 {dp}, {sp}, {bp}, {dp} op_sel_hi:[1,0,1]"] * 8,
+ "pk_mul vgpr": ["v_pk_mul_f32 {dp}, {ap}, {bp}"] * 8,
+ "pk_add vgpr": ["v_pk_add_f32 {dp}, {ap}, {bp}"] * 8,
+ "cmp vgpr -> vcc": ["v_cmp_gt_f32_e32 vcc, {a}, {d}"] * 8,
+ "cmp sgpr -> vcc": ["v_cmp_gt_f32_e32 vcc, {s}, {d}"] * 8,
+ "alt fma/mul": ["v_fma_f32 {d}, {a}, {b}, {b}", "v_mul_f32_e32 {d}, {a}, {b}"] * 4,
+ "alt fma/mul/mul/mul": ["v_fma_f32 {d}, {a}, {b}, {b}", "v_mul_f32_e32 {d}, {a}, {b}", "v_mul_f32_e32 {d}, {a}, {b}", "v_mul_f32_e32 {d}, {a}, {b}"] * 2,
+ "alt pk_fma/mul": ["v_pk_fma_f32 {dp}, {ap}, {bp}, {bp}", "v_mul_f32_e32 {d}, {a}, {b}"] * 4,
+ "alt pk_fma/mul/mul/mul": ["v_pk_fma_f32 {dp}, {ap}, {bp}, {bp}", "v_mul_f32_e32 {d}, {a}, {b}", "v_mul_f32_e32 {d}, {a}, {b}", "v_mul_f32_e32 {d}, {a}, {b}"] * 2,
+ "alt pk_fma(sgpr)/mul": ["v_pk_fma_f32 {dp}, {sp}, {bp}, {bp}", "v_mul_f32_e32 {d}, {a}, {b}"] * 4,
+ "alt fma(sgpr)/mul": ["v_fma_f32 {d}, {s}, {b}, {b}", "v_mul_f32_e32 {d}, {a}, {b}"] * 4,
+ "alt cmp/mul": ["v_cmp_gt_f32_e32 vcc, {a}, {d}", "v_mul_f32_e32 {d}, {a}, {b}"] * 4,
+ "alt fma/fma(sgpr)": ["v_fma_f32 {d}, {a}, {b}, {b}", "v_fma_f32 {d}, {s}, {b}, {b}"] * 4,
+ "alt mul/add": ["v_mul_f32_e32 {d}, {a}, {b}", "v_add_f32_e32 {d}, {a}, {b}"] * 4,
+ "mul dependent chain (1 reg)": ["v_mul_f32_e32 {d0}, {d0}, {b}"] * 8,
+ "fma dependent chain (1 reg)": ["v_fma_f32 {d0}, {d0}, {b}, {b}"] * 8,
+}
+out = ['#include <hip/hip_runtime.h>', '#include <cstdio>', 'typedef float f2 __attribute__((ext_vector_type(2)));',
+       'template <int V> __global__ __launch_bounds__(256) void k(float *out, int iters, float sa, float sb) {',
+       '  float a = threadIdx.x * 1e-3f, b = 1.0001f; f2 ap = {a, a}, bp = {b, b};',
+       '  f2 r0 = {0,0}, r1 = {0,0}, r2 = {0,0}, r3 = {0,0}, r4 = {0,0}, r5 = {0,0}, r6 = {0,0}, r7 = {0,0};',
+       '  float q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, q6 = 0, q7 = 0;',
+       '  for (int it = 0; it < iters; ++it) {']
+names = list(V)
+for vi, name in enumerate(names):
+    lines = []
+    for rep in range(8):
+        for k, t in enumerate(V[name]):
+            lines.append(t.format(d="%%%d" % k, dp="%%%d" % (8 + k), d0="%0", a="%16", b="%17", ap="%18", bp="%19",
+                                  s="s20", sp="s[20:21]"))
+    body = "\\n ".join(lines)
+    # destinations are 64-bit pairs; plain f32 ops write the low half
+    out.append('    if (V == %d) asm volatile("%s" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "v"(ap), "v"(bp) : "vcc");' % (vi, body))
+out += ['  }', '  out[blockIdx.x * 256 + threadIdx.x] = r0.x + r1.x + r2.x + r3.x + r4.y + r5.x + r6.x + r7.x + q0 + q1 + q2 + q3 + q4 + q5 + q6 + q7;', '}',
+        'template <int V> void run(const char *name, float *out) {',
+        '  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); const int iters = 10000;',
+        '  printf("%-36s", name);',
+        '  for (int w : {1, 2, 4, 8}) { int blocks = 256 * w;',
+        '    hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(256), 0, 0, out, 100, 0.5f, 0.25f); (void)hipDeviceSynchronize();',
+        '    (void)hipEventRecord(e0); hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(256), 0, 0, out, iters, 0.5f, 0.25f);',
+        '    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); float ms; (void)hipEventElapsedTime(&ms, e0, e1);',
+        '    printf("  w=%d: %5.2f", w, ms * 1e-3 * 2.4e9 / ((double)w * iters * 64.0)); }',
+        '  printf("\\n"); }',
+        'int main() { float *out; (void)hipMalloc(&out, 256 * 8 * 256 * 4);']
+for vi, name in enumerate(names):
+    out.append('  run<%d>("%s", out);' % (vi, name))
+out += ['  return 0; }']
+open("tools/ub_issue2.hip", "w").write("\n".join(out) + "\n")

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Development aid: run one render step with a library built with -DRTK_STATS
+and print the wave-level event counters.  usage: stats_probe.py <lib.so> [workload] [spp]"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["RT_HIP_LIBRARY"] = os.path.abspath(sys.argv[1])
+from raytracing_amd import Renderer, load_tables, make_params, workloads  # noqa: E402
+
+name = sys.argv[2] if len(sys.argv) > 2 else "c4"
+sps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+wl = workloads.workload(name)
+r = Renderer(0, load_tables())
+r.set_scene(wl["flat"]); r.set_camera(wl["camera"]); r.begin_frame(wl["width"], wl["height"])
+r.timer_start()
+r.render(make_params(wl["width"], wl["height"], spp=wl["spp"], sample_begin=0, sample_count=sps))
+ms = r.timer_stop()
+out = (C.c_uint64 * 8)()
+r._lib.rtdbg_read_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+assert r._lib.rtdbg_read_counters(r._ctx, out) == 0
+names = ["segments", "wave_scans", "batches", "batches_any_pass", "exact_wave", "exact_lane", "-", "-"]
+v = list(out)
+print("ms", round(ms, 2), dict(zip(names, v)))
+if v[1]:
+    print("lane utilisation %.3f  batches passing %.4f  exact per wave-scan %.1f  lanes per exact %.2f"
+          % (v[0] / (64.0 * v[1]), v[3] / max(1, v[2]), v[4] / v[1], v[5] / max(1, v[4])))
