@@ -5,12 +5,14 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "rt_device.h"
+#include "rt_scene_build.h"
 
 namespace {
 
@@ -84,27 +86,6 @@ int upload(Ctx *c, const std::vector<T> &host, const T **dev_out) {
         HIP_TRY(c, hipMemcpyAsync(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
     *dev_out = static_cast<const T *>(d);
     return RT_OK;
-}
-
-inline float bits_to_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
-
-struct ListEntry { int kind = -1; uint32_t k = 0; };
-
-// Threshold of the kernel's conservative sphere rejection test (see cull_pass):
-//   thr = r^2 (1+eps) - |c|^2 (1-eps),  eps = 2^-16,
-// evaluated in double and rounded UP to float so rounding can only make the
-// test reject less.  Spheres whose magnitudes would leave the range where the
-// kernel's error bound holds (squares near overflow or underflow) get +inf:
-// never rejected, always handed to the exact test.
-float cull_threshold(float cx, float cy, float cz, float r) {
-    const double eps = 1.0 / 65536.0;
-    const double c2 = (double)cx * cx + (double)cy * cy + (double)cz * cz;
-    const double r2 = (double)r * r;
-    if (!(c2 < 1e30) || !(r2 < 1e30) || !(c2 + r2 > 1e-24)) return INFINITY;
-    const double thr = r2 * (1.0 + eps) - c2 * (1.0 - eps);
-    float f = (float)thr;
-    if ((double)f < thr) f = std::nextafterf(f, INFINITY);
-    return f;
 }
 
 // number of 8-row bands b < ceil(H/8) with b % stride == begin
@@ -183,123 +164,33 @@ int rt_upload_scene(rt_ctx *ctx, const rt_scene *s) {
     Ctx *c = C(ctx);
     if (!c) return RT_E_BADARG;
     if (!s) return fail(c, RT_E_BADARG, "rt_upload_scene: scene is null");
-    const uint64_t n64 = (uint64_t)s->n_spheres + s->n_planes + s->n_cubes + s->n_tris;
-    if (n64 > 0x7fffffffu) return fail(c, RT_E_BADARG, "rt_upload_scene: too many primitives");
-    const uint32_t n = (uint32_t)n64;
-    if ((s->n_spheres && !(s->sph_cx && s->sph_cy && s->sph_cz && s->sph_r && s->sph_mat && s->sph_id)) ||
-        (s->n_planes && !(s->pl_nx && s->pl_ny && s->pl_nz && s->pl_px && s->pl_py && s->pl_pz && s->pl_mat && s->pl_id)) ||
-        (s->n_cubes && !(s->cb_cx && s->cb_cy && s->cb_cz && s->cb_w && s->cb_h && s->cb_d && s->cb_mat && s->cb_id)) ||
-        (s->n_tris && !(s->tri_v0x && s->tri_v0y && s->tri_v0z && s->tri_v1x && s->tri_v1y && s->tri_v1z &&
-                        s->tri_v2x && s->tri_v2y && s->tri_v2z && s->tri_mat && s->tri_id)) ||
-        (s->n_materials && !(s->mat_kind && s->mat_r && s->mat_g && s->mat_b && s->mat_param)))
-        return fail(c, RT_E_BADARG, "rt_upload_scene: null array in a non-empty group");
-    if (n > 0 && s->n_materials == 0) return fail(c, RT_E_BADARG, "rt_upload_scene: primitives but no materials");
-    for (uint32_t m = 0; m < s->n_materials; ++m)
-        if (s->mat_kind[m] < RT_METAL || s->mat_kind[m] > RT_DIELECTRIC)
-            return fail(c, RT_E_BADARG, "rt_upload_scene: unknown material kind");
-
-    // list order: ids of all groups must be a permutation of 0..n-1
-    std::vector<ListEntry> list;
-    try { list.resize(n); } catch (...) { return fail(c, RT_E_OOM, "rt_upload_scene: out of host memory"); }
-    auto place = [&](uint32_t id, uint32_t mat, int kind, uint32_t k) -> bool {
-        if (id >= n || list[id].kind != -1 || mat >= s->n_materials) return false;
-        list[id].kind = kind; list[id].k = k;
-        return true;
-    };
-    bool ok = true;
-    for (uint32_t k = 0; ok && k < s->n_spheres; ++k) ok = place(s->sph_id[k], s->sph_mat[k], DEV_SPHERE, k);
-    for (uint32_t k = 0; ok && k < s->n_planes; ++k) ok = place(s->pl_id[k], s->pl_mat[k], DEV_PLANE, k);
-    for (uint32_t k = 0; ok && k < s->n_cubes; ++k) ok = place(s->cb_id[k], s->cb_mat[k], DEV_CUBE, k);
-    for (uint32_t k = 0; ok && k < s->n_tris; ++k) ok = place(s->tri_id[k], s->tri_mat[k], DEV_TRI, k);
-    if (!ok) return fail(c, RT_E_BADARG, "rt_upload_scene: ids are not a permutation of the list, or a material index is out of range");
-
-    std::vector<uint4> runs;
-    std::vector<float4> sph_geom, sph_cull, planes, cubes, tris, mat_albedo;
-    std::vector<uint32_t> sph_mat;
-    std::vector<int32_t> mat_kind;
-    uint32_t need_ff_shared = 0;
+    // RT_HIP_FLAT_SCAN=1 keeps long runs in list order (no bounding-sphere tree):
+    // the brute-force scan whose work matches the reference's linear list.
+    const char *flat = std::getenv("RT_HIP_FLAT_SCAN");
+    const bool use_tree = !(flat && flat[0] && flat[0] != '0');
+    HostScene hs;
+    std::string err;
+    int rc;
     try {
-        for (uint32_t m = 0; m < s->n_materials; ++m) {
-            mat_albedo.push_back(make_float4(s->mat_r[m], s->mat_g[m], s->mat_b[m], s->mat_param[m]));
-            mat_kind.push_back(s->mat_kind[m]);
-        }
-        auto pad_spheres = [&]() {
-            while (sph_geom.size() % DEV_SPHERE_BATCH) {
-                // a sphere no ray can reach: the conservative test always rejects it
-                sph_geom.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
-                sph_cull.push_back(make_float4(0.f, 0.f, 0.f, -INFINITY));   // g > -inf: always rejected
-                sph_mat.push_back(0);
-            }
-        };
-        for (uint32_t id = 0; id < n; ++id) {
-            const int kind = list[id].kind;
-            const uint32_t k = list[id].k;
-            uint32_t slot = 0;
-            if (kind == DEV_SPHERE) slot = (uint32_t)sph_geom.size();
-            else if (kind == DEV_PLANE) slot = (uint32_t)(planes.size() / 2);
-            else if (kind == DEV_CUBE) slot = (uint32_t)(cubes.size() / 4);
-            else slot = (uint32_t)(tris.size() / 3);
-            if (runs.empty() || (int)runs.back().x != kind) {
-                if (kind == DEV_SPHERE) { pad_spheres(); slot = (uint32_t)sph_geom.size(); }
-                runs.push_back(make_uint4((uint32_t)kind, slot, 0u, id));
-            }
-            runs.back().z += 1;
-            if (kind == DEV_SPHERE) {
-                const float cx = s->sph_cx[k], cy = s->sph_cy[k], cz = s->sph_cz[k], r = s->sph_r[k];
-                sph_geom.push_back(make_float4(cx, cy, cz, r));
-                sph_cull.push_back(make_float4(cx, cy, cz, cull_threshold(cx, cy, cz, r)));
-                sph_mat.push_back(s->sph_mat[k]);
-            } else if (kind == DEV_PLANE) {
-                planes.push_back(make_float4(s->pl_nx[k], s->pl_ny[k], s->pl_nz[k], bits_to_float(s->pl_mat[k])));
-                planes.push_back(make_float4(s->pl_px[k], s->pl_py[k], s->pl_pz[k], 0.f));
-            } else if (kind == DEV_CUBE) {
-                // Cube::new, src/geometry/mod.rs:146-154: corners from center and extents;
-                // w/2 is also what Cube::hit divides by (:213-215)
-                const float cx = s->cb_cx[k], cy = s->cb_cy[k], cz = s->cb_cz[k];
-                const float w = s->cb_w[k], h = s->cb_h[k], d = s->cb_d[k];
-                const float hw = w / 2.0f, hh = h / 2.0f, hd = d / 2.0f;
-                const float c0x = cx + (-w / 2.0f), c0y = cy + (-h / 2.0f), c0z = cz + (-d / 2.0f);
-                const float c1x = cx + hw, c1y = cy + hh, c1z = cz + hd;
-                cubes.push_back(make_float4(cx, cy, cz, bits_to_float(s->cb_mat[k])));
-                cubes.push_back(make_float4(hw, hh, hd, 0.f));
-                cubes.push_back(make_float4(c0x, c0y, c0z, 0.f));
-                cubes.push_back(make_float4(c1x, c1y, c1z, 0.f));
-                if (s->mat_kind[s->cb_mat[k]] == RT_DIELECTRIC) need_ff_shared = 1;
-            } else {
-                const float ax = s->tri_v0x[k], ay = s->tri_v0y[k], az = s->tri_v0z[k];
-                const float e1x = s->tri_v1x[k] - ax, e1y = s->tri_v1y[k] - ay, e1z = s->tri_v1z[k] - az;
-                const float e2x = s->tri_v2x[k] - ax, e2y = s->tri_v2y[k] - ay, e2z = s->tri_v2z[k] - az;
-                tris.push_back(make_float4(ax, ay, az, bits_to_float(s->tri_mat[k])));
-                tris.push_back(make_float4(e1x, e1y, e1z, 0.f));
-                tris.push_back(make_float4(e2x, e2y, e2z, 0.f));
-            }
-        }
-        pad_spheres();
+        rc = build_host_scene(s, use_tree, hs, err);
     } catch (const std::bad_alloc &) {
         return fail(c, RT_E_OOM, "rt_upload_scene: out of host memory");
     }
-
-    // The kernel reads the rejection records two spheres at a time:
-    // {cx0,cx1, cy0,cy1, cz0,cz1, thr0,thr1}.  Runs start at even slots
-    // (padded to multiples of DEV_SPHERE_BATCH), so pairs never straddle runs.
-    for (size_t k = 0; k + 1 < sph_cull.size(); k += 2) {
-        const float4 a = sph_cull[k], b = sph_cull[k + 1];
-        sph_cull[k] = make_float4(a.x, b.x, a.y, b.y);
-        sph_cull[k + 1] = make_float4(a.z, b.z, a.w, b.w);
-    }
+    if (rc != RT_OK) return fail(c, rc, "rt_upload_scene: " + err);
 
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // no render may still read the old scene
     free_scene(c);
     DevScene d{};
-    d.n_runs = (uint32_t)runs.size();
-    d.need_ff_shared = need_ff_shared;
-    int rc;
-    if ((rc = upload(c, runs, &d.runs)) != RT_OK || (rc = upload(c, sph_geom, &d.sph_geom)) != RT_OK ||
-        (rc = upload(c, sph_cull, &d.sph_cull)) != RT_OK || (rc = upload(c, sph_mat, &d.sph_mat)) != RT_OK ||
-        (rc = upload(c, planes, &d.planes)) != RT_OK || (rc = upload(c, cubes, &d.cubes)) != RT_OK ||
-        (rc = upload(c, tris, &d.tris)) != RT_OK || (rc = upload(c, mat_albedo, &d.mat_albedo)) != RT_OK ||
-        (rc = upload(c, mat_kind, &d.mat_kind)) != RT_OK) {
+    d.n_runs = (uint32_t)hs.runs.size();
+    d.need_ff_shared = hs.need_ff_shared;
+    if ((rc = upload(c, hs.runs, &d.runs)) != RT_OK || (rc = upload(c, hs.sph_geom, &d.sph_geom)) != RT_OK ||
+        (rc = upload(c, hs.sph_mat, &d.sph_mat)) != RT_OK || (rc = upload(c, hs.sph_id, &d.sph_id)) != RT_OK ||
+        (rc = upload(c, hs.planes, &d.planes)) != RT_OK || (rc = upload(c, hs.cubes, &d.cubes)) != RT_OK ||
+        (rc = upload(c, hs.tris, &d.tris)) != RT_OK || (rc = upload(c, hs.tri_id, &d.tri_id)) != RT_OK ||
+        (rc = upload(c, hs.cull_rec, &d.cull_rec)) != RT_OK ||
+        (rc = upload(c, hs.tree_rec, &d.tree_rec)) != RT_OK || (rc = upload(c, hs.order, &d.order)) != RT_OK ||
+        (rc = upload(c, hs.mat_albedo, &d.mat_albedo)) != RT_OK || (rc = upload(c, hs.mat_kind, &d.mat_kind)) != RT_OK) {
         std::string keep = c->err;
         free_scene(c);
         c->err = keep;

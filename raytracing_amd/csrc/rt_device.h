@@ -11,28 +11,53 @@
 // primitive kinds of a run; values match the order the C ABI lists the groups
 enum { DEV_SPHERE = 0, DEV_PLANE = 1, DEV_CUBE = 2, DEV_TRI = 3 };
 
-// spheres of one run are padded to a multiple of this many entries with
-// spheres that can never be hit, so the scan can take them in fixed batches
-#define DEV_SPHERE_BATCH 16u
+// how a run is scanned
+enum { RUN_EXACT = 0, RUN_FLAT = 1, RUN_TREE = 2 };
 // sphere runs at least this long go through the conservative rejection test
 #define DEV_CULL_MIN_RUN 32u
+// sphere / triangle runs at least this long get the bounding-sphere tree
+#define DEV_TREE_MIN_RUN 64u
+#define DEV_MAX_LEVELS 8u
 
-// The primitive list in device memory.  The reference's insertion-ordered
-// Vec<Box<dyn Hittable>> (src/geometry/mod.rs:228-238) is cut into maximal
-// runs of one kind; a run's primitives lie contiguously in that kind's array,
-// in list order.  All arrays are read with wave-uniform indices.
+// One maximal run of same-kind primitives of the reference's insertion-ordered
+// Vec<Box<dyn Hittable>> (src/geometry/mod.rs:228-238).  128 bytes, read with two
+// scalar loads.  Rejection records live in DevScene::cull_rec, addressed in steps
+// of eight records (128 bytes); level 0 holds the primitives' own records, level
+// L+1 one bounding ball per step of level L.
+struct DevRun {
+    uint32_t kind;        // DEV_*
+    uint32_t first;       // first slot in the kind's arrays
+    uint32_t count;       // primitives in the run
+    uint32_t id0;         // list position of the run's first primitive
+    uint32_t mode;        // RUN_*
+    uint32_t n_levels;    // RUN_FLAT: 1; RUN_TREE: levels of the tree
+    uint32_t top_steps;   // steps of the top level (RUN_FLAT: all steps, an even number)
+    uint32_t order_base;  // DevScene::order + order_base: list position in run -> slot offset
+    uint32_t level_base[DEV_MAX_LEVELS];   // first step of each level
+    float level_keep[DEV_MAX_LEVELS];      // 1 - eps of each level
+    float reach;          // RUN_TREE: max over balls of |centre| + radius
+    uint32_t pad[7];
+};
+
+// The primitive list in device memory.  All arrays are read with wave-uniform
+// indices except where a lane fetches the primitive it finally hit.
 struct DevScene {
-    const uint4 *runs;        // {kind, first slot, count, list id of the first}
+    const DevRun *runs;
     uint32_t n_runs;
     uint32_t need_ff_shared;  // some Cube has a Dielectric material: its front_face
                               // is inherited from the previously accepted hit
-    const float4 *sph_geom;   // cx, cy, cz, radius
-    const float4 *sph_cull;   // conservative-test records, two spheres per 8 floats:
-                              // {cx0,cx1, cy0,cy1, cz0,cz1, thr0,thr1}
-    const uint32_t *sph_mat;
+    const float4 *sph_geom;   // cx, cy, cz, radius                  (by slot)
+    const uint32_t *sph_mat;  //                                     (by slot)
+    const uint32_t *sph_id;   // list position                       (by slot)
     const float4 *planes;     // 2 per plane: {n, material bits}, {point, 0}
     const float4 *cubes;      // 4 per cube: {center, material bits}, {w/2,h/2,d/2,0}, {corner0,0}, {corner1,0}
     const float4 *tris;       // 3 per triangle: {v0, material bits}, {e1,0}, {e2,0}
+    const uint32_t *tri_id;   // list position                       (by slot)
+    const float4 *cull_rec;   // RUN_FLAT rejection records, 8 float4 per step of eight balls:
+                              // four pairs {cx0,cx1, cy0,cy1}{cz0,cz1, thr0,thr1}
+    const float4 *tree_rec;   // RUN_TREE records, 10 float4 per step: {cx0,cx1,cy0,cy1} x4,
+                              // {cz0,cz1,thr0,thr1} x4, {r0..r3}, {r4..r7}
+    const uint32_t *order;    // see DevRun::order_base
     const float4 *mat_albedo; // r, g, b, param
     const int32_t *mat_kind;
 };

@@ -66,21 +66,23 @@ constexpr uint32_t GOLDEN32 = 0x9E3779B9u;
 
 // Scene arrays are read through the constant address space: together with a
 // wave-uniform index this makes the compiler fetch them with scalar loads
-// (s_load_dwordx4 into SGPRs) instead of 64 identical vector loads.  The arrays
-// are never written while a render kernel runs.
+// (s_load_dwordx4/x16 into SGPRs) instead of 64 identical vector loads.  The
+// arrays are never written while a render kernel runs.
 typedef float f4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 typedef float f16 __attribute__((ext_vector_type(16)));
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u16v __attribute__((ext_vector_type(16)));
 #define RT_CONST_AS __attribute__((address_space(4)))
 template <typename T, typename S>
 __device__ __forceinline__ const RT_CONST_AS T *const_ptr(const S *p) {
     return (const RT_CONST_AS T *)(uintptr_t)p;
 }
 struct SceneView {
-    const RT_CONST_AS u4 *runs;
-    const RT_CONST_AS f4 *sph_geom, *sph_cull, *planes, *cubes, *tris, *mat_albedo;
-    const RT_CONST_AS uint32_t *sph_mat;
+    const RT_CONST_AS u16v *runs;         // two per DevRun
+    const RT_CONST_AS f4 *sph_geom, *planes, *cubes, *tris, *mat_albedo;
+    const RT_CONST_AS f16 *cull_rec;      // RUN_FLAT: two per step of eight records
+    const RT_CONST_AS f4 *tree_rec;       // RUN_TREE: ten per step of eight records
+    const RT_CONST_AS uint32_t *sph_mat, *sph_id, *tri_id, *order;
     const RT_CONST_AS int32_t *mat_kind;
     uint32_t n_runs, need_ff_shared;
     unsigned long long *stats;   // fr.segments; slots 1..7 are instrumentation (RTK_STATS builds)
@@ -88,27 +90,49 @@ struct SceneView {
 __device__ __forceinline__ SceneView view_of(const DevScene &sc, unsigned long long *stats) {
     SceneView v;
     v.stats = stats;
-    v.runs = const_ptr<u4>(sc.runs);
+    v.runs = const_ptr<u16v>(sc.runs);
     v.sph_geom = const_ptr<f4>(sc.sph_geom);
-    v.sph_cull = const_ptr<f4>(sc.sph_cull);
     v.planes = const_ptr<f4>(sc.planes);
     v.cubes = const_ptr<f4>(sc.cubes);
     v.tris = const_ptr<f4>(sc.tris);
     v.mat_albedo = const_ptr<f4>(sc.mat_albedo);
+    v.cull_rec = const_ptr<f16>(sc.cull_rec);
+    v.tree_rec = const_ptr<f4>(sc.tree_rec);
     v.sph_mat = const_ptr<uint32_t>(sc.sph_mat);
+    v.sph_id = const_ptr<uint32_t>(sc.sph_id);
+    v.tri_id = const_ptr<uint32_t>(sc.tri_id);
+    v.order = const_ptr<uint32_t>(sc.order);
     v.mat_kind = const_ptr<int32_t>(sc.mat_kind);
     v.n_runs = sc.n_runs;
     v.need_ff_shared = sc.need_ff_shared;
+    return v;
+}
+// the words of a DevRun as the two scalar loads deliver them
+struct RunView {
+    uint32_t kind, first, count, id0, mode, n_levels, top_steps, order_base;
+    u16v lo, hi;
+    __device__ __forceinline__ uint32_t level_base(uint32_t L) const { return lo[8 + L]; }
+    __device__ __forceinline__ float level_keep(uint32_t L) const { return __uint_as_float(hi[L]); }
+};
+__device__ __forceinline__ RunView load_run(const SceneView &sc, uint32_t r) {
+    RunView v;
+    v.lo = sc.runs[2 * r];
+    v.hi = sc.runs[2 * r + 1];
+    v.kind = v.lo.s0; v.first = v.lo.s1; v.count = v.lo.s2; v.id0 = v.lo.s3;
+    v.mode = v.lo.s4; v.n_levels = v.lo.s5; v.top_steps = v.lo.s6; v.order_base = v.lo.s7;
     return v;
 }
 
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int TILE = 8;   // 8x8 pixels per wavefront
 
+struct TreeTable { uint32_t base[DEV_MAX_LEVELS]; float keep[DEV_MAX_LEVELS]; };
+
 struct Lds {
     float disc[128];                                    // src/denoising/mod.rs:55
     float sphere[768];                                  // src/denoising/mod.rs:59
     uint32_t mat_stack[WAVES_PER_BLOCK][RT_MAX_BOUNCES][64];
+    TreeTable tree[WAVES_PER_BLOCK];                    // per-level constants of the run being walked
 };
 
 struct Ray { V3 o, d; };
@@ -160,8 +184,18 @@ struct Hit {
     bool ff;        // front_face as the shared temp record held it at accept time
 };
 
-// Sphere::hit, src/geometry/mod.rs:60-94, up to the point where the hit is
-// accepted; h.t plays closest_so_far.  `a` is |dir|^2 (:63).
+// ----------------------------------------------------------------------
+// Exact primitive tests.  They update (h.t, h.kind, h.slot, h.id) like the
+// reference's list loop updates closest_so_far and its record.  A scan that
+// does not visit a run in list order (the bounding-sphere tree) must still
+// end with the primitive the list-order scan ends with: among equal hit
+// distances the reference keeps the LATER sphere / plane / triangle
+// (`t_max < root` rejects, equality accepts, src/geometry/mod.rs:74,116), so
+// an equal-distance candidate with a smaller list position than the current
+// holder is refused here.  In a list-order scan positions only grow and the
+// extra condition never fires.
+// ----------------------------------------------------------------------
+// Sphere::hit, src/geometry/mod.rs:60-94; `a` is |dir|^2 (:63)
 __device__ __forceinline__ void sphere_exact(const SceneView &sc, uint32_t slot, int32_t id, const Ray &ray,
                                              float a, float t_min, Hit &h, bool &ff_shared) {
     const f4 g = sc.sph_geom[slot];   // cx, cy, cz, radius
@@ -176,6 +210,7 @@ __device__ __forceinline__ void sphere_exact(const SceneView &sc, uint32_t slot,
         root = (-half_b + d_sqrt) / a;
         if (root < t_min || h.t < root) return;
     }
+    if (root == h.t && id < h.id) return;
     h.t = root; h.kind = DEV_SPHERE; h.slot = slot; h.id = id;
     if (sc.need_ff_shared) {
         V3 p = ray.o + ray.d * root;
@@ -183,85 +218,291 @@ __device__ __forceinline__ void sphere_exact(const SceneView &sc, uint32_t slot,
         ff_shared = dot(ray.d, outward) < 0.0f;
     }
 }
+// Triangle (defined by rt_hip.h, absent from the reference)
+__device__ __forceinline__ void tri_exact(const SceneView &sc, uint32_t slot, int32_t id, const Ray &ray,
+                                          float t_min, Hit &h, bool &ff_shared) {
+    const f4 v0 = sc.tris[3 * slot];
+    const f4 e1 = sc.tris[3 * slot + 1];
+    const f4 e2 = sc.tris[3 * slot + 2];
+    V3 E1 = mk(e1.x, e1.y, e1.z), E2 = mk(e2.x, e2.y, e2.z);
+    V3 hh = cross(ray.d, E2);
+    float det = dot(E1, hh);
+    if (det == 0.0f) return;
+    float f = 1.0f / det;
+    V3 s = ray.o - mk(v0.x, v0.y, v0.z);
+    float u = f * dot(s, hh);
+    if (u < 0.0f || u > 1.0f) return;
+    V3 q = cross(s, E1);
+    float v = f * dot(ray.d, q);
+    if (v < 0.0f || u + v > 1.0f) return;
+    float t = f * dot(E2, q);
+    if (t < t_min || h.t < t) return;
+    if (t == h.t && id < h.id) return;
+    h.t = t; h.kind = DEV_TRI; h.slot = slot; h.id = id;
+    if (sc.need_ff_shared) {
+        V3 outward = unit(cross(E1, E2));
+        ff_shared = dot(ray.d, outward) < 0.0f;
+    }
+}
 
 // ----------------------------------------------------------------------
-// Conservative sphere rejection.  With u the unit direction, the squared
-// distance from a centre c to the ray's line is |c-o|^2 - ((c-o).u)^2; the
-// sphere cannot be hit when that exceeds r^2.  Expanded so that no per-sphere
-// subtraction is needed:
+// Conservative ball rejection.  With u the unit direction, the squared
+// distance from a centre c to the ray's line is |c-o|^2 - ((c-o).u)^2; a ball
+// of radius r cannot be hit when that exceeds r^2.  Expanded so that no
+// per-ball subtraction is needed:
 //     g = |o|^2 (1-eps) - 2 o.c - ((c.u) - (o.u))^2        (7 fused ops, packed two
-//                                                            spheres per v_pk_fma_f32)
+//                                                            balls per v_pk_fma_f32)
 //     reject  <=>  g > r^2 (1+eps) - |c|^2 (1-eps) = thr   (1 compare)
 // i.e. dist^2 - r^2 > eps (|o|^2 + |c|^2 + r^2).  Sphere::hit misses (its
 // discriminant, evaluated in f32 without fusing, is negative) whenever
 // dist^2 - r^2 > 19.5 ulp |o-c|^2; the rounding of the seven fused ops, of
 // u, o.u and thr adds at most 30 ulp (|o|+|c|)^2, and (|o|+|c|)^2 <=
 // 2(|o|^2+|c|^2), so eps = 2^-16 = 256 ulp covers both with a factor 2.6 to
-// spare.  The test never ACCEPTS anything: survivors run Sphere::hit itself.
+// spare.  Bounding balls of the tree use larger eps (see the host-side
+// builder); eps enters through thr and through the per-level factor `keep`.
+// The test never ACCEPTS anything: survivors run the exact test itself.
 // NaN or infinite intermediates compare false and survive.
 // ----------------------------------------------------------------------
 struct Cull { float ux, uy, uz, nou, ax, ay, az, oo; };
-constexpr float CULL_EPS = 1.0f / 65536.0f;
 
-__device__ __forceinline__ Cull cull_setup(const Ray &ray, float a, bool tracing) {
+__device__ __forceinline__ Cull cull_setup(const Ray &ray, float a) {
     Cull c;
     const float len = __builtin_sqrtf(a);
     c.ux = ray.d.x / len; c.uy = ray.d.y / len; c.uz = ray.d.z / len;
     c.nou = -__builtin_fmaf(ray.o.x, c.ux, __builtin_fmaf(ray.o.y, c.uy, ray.o.z * c.uz));
     c.ax = -2.0f * ray.o.x; c.ay = -2.0f * ray.o.y; c.az = -2.0f * ray.o.z;
-    const float oo = __builtin_fmaf(ray.o.x, ray.o.x, __builtin_fmaf(ray.o.y, ray.o.y, ray.o.z * ray.o.z));
-    // lanes with no ray to trace reject everything
-    c.oo = tracing ? oo * (1.0f - CULL_EPS) : __builtin_inff();
+    c.oo = __builtin_fmaf(ray.o.x, ray.o.x, __builtin_fmaf(ray.o.y, ray.o.y, ray.o.z * ray.o.z));
     return c;
 }
-// g of two spheres at once: seven v_pk_fma_f32, each taking one SGPR pair
-// (the same coordinate of both spheres) and ray values broadcast from one VGPR.
-// A sphere may be hit, and goes to the exact test, unless g > thr.
-__device__ __forceinline__ f2 cull_pair(const Cull &c, f2 cx, f2 cy, f2 cz) {
+// g of two balls at once: seven v_pk_fma_f32, each taking one SGPR pair (the
+// same coordinate of both balls) and ray values broadcast from one VGPR.
+// oo_keep = |o|^2 (1-eps) for participating lanes, +inf for lanes that must
+// reject everything.
+__device__ __forceinline__ f2 cull_pair(const Cull &c, float oo_keep, f2 cx, f2 cy, f2 cz) {
     const f2 ux = {c.ux, c.ux}, uy = {c.uy, c.uy}, uz = {c.uz, c.uz}, nou = {c.nou, c.nou};
-    const f2 ax = {c.ax, c.ax}, ay = {c.ay, c.ay}, az = {c.az, c.az}, oo = {c.oo, c.oo};
+    const f2 ax = {c.ax, c.ax}, ay = {c.ay, c.ay}, az = {c.az, c.az}, oo = {oo_keep, oo_keep};
     const f2 m = __builtin_elementwise_fma(cx, ux, __builtin_elementwise_fma(cy, uy, __builtin_elementwise_fma(cz, uz, nou)));
     const f2 w = __builtin_elementwise_fma(cx, ax, __builtin_elementwise_fma(cy, ay, __builtin_elementwise_fma(cz, az, oo)));
     return __builtin_elementwise_fma(-m, m, w);
 }
 
-// One step of the long-run sphere scan: eight spheres, given as four pair
-// records {cx0,cx1, cy0,cy1, cz0,cz1, thr0,thr1} in ra and rb (SGPRs), starting at
-// position `first` of the run.
-__device__ __forceinline__ void cull_step(const SceneView &sc, const Cull &cull, const f16 ra, const f16 rb,
-                                          const u4 run, uint32_t first, const Ray &ray, float a, float t_min,
-                                          Hit &h, bool &ff_shared) {
-    const f2 g01 = cull_pair(cull, ra.s01, ra.s23, ra.s45);
-    const f2 g23 = cull_pair(cull, ra.s89, ra.sab, ra.scd);
-    const f2 g45 = cull_pair(cull, rb.s01, rb.s23, rb.s45);
-    const f2 g67 = cull_pair(cull, rb.s89, rb.sab, rb.scd);
+// One step: eight balls given as four pair records {cx0,cx1, cy0,cy1, cz0,cz1,
+// thr0,thr1} in ra and rb (SGPRs).  Returns, per lane, the bit mask of balls the
+// lane could not reject; any_bits gets the wave-wide union (uniform).
+__device__ __forceinline__ uint32_t cull_step(const Cull &cull, float oo_keep, const f16 ra, const f16 rb,
+                                              uint32_t &any_bits) {
+    const f2 g01 = cull_pair(cull, oo_keep, ra.s01, ra.s23, ra.s45);
+    const f2 g23 = cull_pair(cull, oo_keep, ra.s89, ra.sab, ra.scd);
+    const f2 g45 = cull_pair(cull, oo_keep, rb.s01, rb.s23, rb.s45);
+    const f2 g67 = cull_pair(cull, oo_keep, rb.s89, rb.sab, rb.scd);
     const bool p0 = !(g01.x > ra.s6), p1 = !(g01.y > ra.s7);
     const bool p2 = !(g23.x > ra.se), p3 = !(g23.y > ra.sf);
     const bool p4 = !(g45.x > rb.s6), p5 = !(g45.y > rb.s7);
     const bool p6 = !(g67.x > rb.se), p7 = !(g67.y > rb.sf);
-    // wave-level "does any lane need the exact test": the compare masks already are
-    // SGPR pairs, so this is a chain of s_or_b64 and one scalar branch
+    // the compare masks already are SGPR pairs: the wave-level "does any lane need
+    // more" is a chain of s_or_b64 and one scalar branch
     const unsigned long long m0 = __builtin_amdgcn_ballot_w64(p0), m1 = __builtin_amdgcn_ballot_w64(p1);
     const unsigned long long m2 = __builtin_amdgcn_ballot_w64(p2), m3 = __builtin_amdgcn_ballot_w64(p3);
     const unsigned long long m4 = __builtin_amdgcn_ballot_w64(p4), m5 = __builtin_amdgcn_ballot_w64(p5);
     const unsigned long long m6 = __builtin_amdgcn_ballot_w64(p6), m7 = __builtin_amdgcn_ballot_w64(p7);
-    RTK_COUNT(sc, 2, 1);
-    if ((m0 | m1 | m2 | m3 | m4 | m5 | m6 | m7) == 0ull) return;
-    // rare (a few percent of the steps): one shared copy of the exact test, run for
-    // the spheres some lane could not reject, in list order
-    RTK_COUNT(sc, 3, 1);
-    const uint32_t lane_bits = (p0 ? 1u : 0u) | (p1 ? 2u : 0u) | (p2 ? 4u : 0u) | (p3 ? 8u : 0u) |
-                               (p4 ? 16u : 0u) | (p5 ? 32u : 0u) | (p6 ? 64u : 0u) | (p7 ? 128u : 0u);
-    const uint32_t any_bits = (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u) | (m3 ? 8u : 0u) |
-                              (m4 ? 16u : 0u) | (m5 ? 32u : 0u) | (m6 ? 64u : 0u) | (m7 ? 128u : 0u);
-    if (first >= run.z) return;                 // a step of padding only
-    const uint32_t left = run.z - first;        // real spheres from here on
+    any_bits = 0u;
+    if ((m0 | m1 | m2 | m3 | m4 | m5 | m6 | m7) == 0ull) return 0u;
+    // rare (a few percent of the steps)
+    any_bits = (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u) | (m3 ? 8u : 0u) |
+               (m4 ? 16u : 0u) | (m5 ? 32u : 0u) | (m6 ? 64u : 0u) | (m7 ? 128u : 0u);
+    return (p0 ? 1u : 0u) | (p1 ? 2u : 0u) | (p2 ? 4u : 0u) | (p3 ? 8u : 0u) |
+           (p4 ? 16u : 0u) | (p5 ? 32u : 0u) | (p6 ? 64u : 0u) | (p7 ? 128u : 0u);
+}
+
+// exact test of the primitives of one leaf step that some lane could not reject
+template <int KIND>
+__device__ __forceinline__ void leaf_exact(const SceneView &sc, const RunView &run, uint32_t first_in_run,
+                                           uint32_t any_bits, uint32_t lane_bits, bool list_order,
+                                           const Ray &ray, float a, float t_min, Hit &h, bool &ff_shared) {
+    if (first_in_run >= run.count) return;          // a step of padding only
+    const uint32_t left = run.count - first_in_run;
 #pragma unroll 1
     for (uint32_t k = 0; k < 8u; ++k) {
         if (((any_bits >> k) & 1u) == 0u || k >= left) continue;
         RTK_COUNT(sc, 4, 1);
-        if ((lane_bits >> k) & 1u)
-            sphere_exact(sc, run.y + first + k, (int32_t)(run.w + first + k), ray, a, t_min, h, ff_shared);
+        const uint32_t slot = run.first + first_in_run + k;
+        const int32_t id = list_order ? (int32_t)(run.id0 + first_in_run + k)
+                                      : (int32_t)(KIND == DEV_SPHERE ? sc.sph_id[slot] : sc.tri_id[slot]);
+        if ((lane_bits >> k) & 1u) {
+            if (KIND == DEV_SPHERE) sphere_exact(sc, slot, id, ray, a, t_min, h, ff_shared);
+            else tri_exact(sc, slot, id, ray, t_min, h, ff_shared);
+        }
+    }
+}
+
+// ----------------------------------------------------------------------
+// RUN_FLAT: a long sphere run in list order, eight spheres per step through
+// the rejection test.  Two steps per trip in ping-pong register sets: the
+// records of the next step are requested BEFORE the current step is computed,
+// so the scalar-cache / L2 latency of the s_load_dwordx16 pair overlaps the
+// arithmetic.  Scalar loads return out of order, the only wait is "all of
+// them"; it sits right before the next request, when the awaited data has had
+// a whole step to arrive.
+// ----------------------------------------------------------------------
+__device__ __forceinline__ void scan_flat(const SceneView &sc, const RunView &run, const Cull &cull, bool tracing,
+                                          const Ray &ray, float a, float t_min, Hit &h, bool &ff_shared) {
+    const float oo_keep = tracing ? cull.oo * run.level_keep(0) : __builtin_inff();
+    const RT_CONST_AS f16 *rec = sc.cull_rec + 2u * run.level_base(0);
+    const uint32_t trips = run.top_steps / 2u;
+    f16 a0 = rec[0], a1 = rec[1];
+    for (uint32_t b = 0; b < trips; ++b) {
+        uint32_t any_bits, lane_bits;
+        asm volatile("; records of the even step have arrived" ::"s"(a0.s0), "s"(a1.s0));
+        __builtin_amdgcn_sched_barrier(0);
+        const f16 b0 = rec[4 * b + 2], b1 = rec[4 * b + 3];
+        __builtin_amdgcn_sched_barrier(0);
+        RTK_COUNT(sc, 2, 2);
+        lane_bits = cull_step(cull, oo_keep, a0, a1, any_bits);
+        if (any_bits) {
+            RTK_COUNT(sc, 3, 1);
+            leaf_exact<DEV_SPHERE>(sc, run, 16u * b, any_bits, lane_bits, true, ray, a, t_min, h, ff_shared);
+        }
+        asm volatile("; records of the odd step have arrived" ::"s"(b0.s0), "s"(b1.s0));
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t nb = (b + 1u < trips) ? b + 1u : b;   // the last trip re-reads itself
+        a0 = rec[4 * nb]; a1 = rec[4 * nb + 1];
+        __builtin_amdgcn_sched_barrier(0);
+        lane_bits = cull_step(cull, oo_keep, b0, b1, any_bits);
+        if (any_bits) {
+            RTK_COUNT(sc, 3, 1);
+            leaf_exact<DEV_SPHERE>(sc, run, 16u * b + 8u, any_bits, lane_bits, true, ray, a, t_min, h, ff_shared);
+        }
+    }
+}
+
+// ----------------------------------------------------------------------
+// RUN_TREE: the run's primitives are stored in a spatially hierarchical order; level 0 of the
+// implicit 8-ary tree holds their own balls, level L+1 one ball per step of
+// level L (children of step s at level L+1 ... are the steps 8s..8s+7 one level
+// down).  Every lane walks the tree for its own ray: per trip each lane with
+// work left fetches ITS node (ten 16-byte loads, 160 bytes), tests the eight
+// child balls, and either descends, runs the exact test on surviving
+// primitives (level 0), or moves on to the next pending sibling.  No stack:
+// the path is the step index itself (parent = s >> 3), the children still to
+// visit are one byte per level in a 64-bit register.  The wave loops until a
+// ballot says no lane has a node left.
+//
+// A child ball is skipped when the RAY (not the line) cannot touch it:
+//   |o|^2 keep - 2 o.c - max((c-o).u, 0)^2 > thr          (misses sideways / lies behind)
+//   (c-o).u - R > closest_so_far * |d| (+ rounding slack)  (lies beyond the best hit)
+// Rays whose numbers could make a hit distance NaN (zero or non-finite
+// direction, NaN closest_so_far inherited from an earlier run) are kept out
+// of the walk and take the run in list order instead, because with NaN the
+// reference's result depends on the visiting order (src/geometry/mod.rs:74:
+// both comparisons fail and the sphere is accepted).
+// ----------------------------------------------------------------------
+template <int KIND>
+__device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &run, const Cull &cull, bool tracing,
+                                          TreeTable &tbl, const Ray &ray, float a, float t_min, Hit &h,
+                                          bool &ff_shared) {
+    const float big = 1e18f;
+    const bool tame = a > 0.0f && a < big && h.t == h.t &&
+                      __builtin_fabsf(ray.o.x) < big && __builtin_fabsf(ray.o.y) < big && __builtin_fabsf(ray.o.z) < big;
+    const bool wild = tracing && !tame;
+    if (__builtin_amdgcn_ballot_w64(wild) != 0ull) {
+        for (uint32_t k = 0; k < run.count; ++k) {
+            const uint32_t slot = run.first + sc.order[run.order_base + k];
+            if (wild) {
+                if (KIND == DEV_SPHERE) sphere_exact(sc, slot, (int32_t)(run.id0 + k), ray, a, t_min, h, ff_shared);
+                else tri_exact(sc, slot, (int32_t)(run.id0 + k), ray, t_min, h, ff_shared);
+            }
+        }
+    }
+    const bool walking = tracing && tame;
+    if (__builtin_amdgcn_ballot_w64(walking) == 0ull) return;
+
+    // per-level constants where a lane can index them by its own level
+#pragma unroll
+    for (uint32_t L = 0; L < DEV_MAX_LEVELS; ++L) { tbl.base[L] = run.lo[8 + L]; tbl.keep[L] = __uint_as_float(run.hi[L]); }
+    const float len = __builtin_sqrtf(a);
+    // slack of the "beyond the best hit" test: (c-o).u is off by < 10 ulp (|o|+|c|)
+    const float far_pad = (__builtin_sqrtf(cull.oo) + __uint_as_float(run.hi[8])) * (1.0f / 1048576.0f);
+    const float far_len = len * (1.0f + 1.0f / 1048576.0f);
+    const uint32_t top = run.n_levels - 1u;
+    const RT_CONST_AS f4 *nodes = sc.tree_rec;
+
+    for (uint32_t ts = 0; ts < run.top_steps; ++ts) {
+        uint32_t L = top, st = ts;
+        unsigned long long pend = 0ull;
+        bool act = walking;
+        while (__builtin_amdgcn_ballot_w64(act) != 0ull) {
+            RTK_COUNT(sc, 2, 1);
+            RTK_COUNT(sc, 5, __builtin_popcountll(__builtin_amdgcn_ballot_w64(act)));
+            RTK_COUNT(sc, 6, __builtin_popcountll(__builtin_amdgcn_ballot_w64(act && L == 0u)));
+            if (act) {
+                const RT_CONST_AS f4 *nd = nodes + 10u * (size_t)(tbl.base[L] + st);
+                const float oo_keep = cull.oo * tbl.keep[L];
+                const float tl = __builtin_fmaf(h.t, far_len, far_pad);   // inf while nothing is hit
+                uint32_t sign_bits = 0u;
+                uint32_t nearest = 0xffffffffu;   // min over surviving children of (distance along the ray | index)
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    const f4 A = nd[pr];          // cx0, cx1, cy0, cy1
+                    const f4 B = nd[4 + pr];      // cz0, cz1, thr0, thr1
+                    const f4 R4 = nd[8 + (pr >> 1)];
+                    const f2 rr = (pr & 1) ? R4.zw : R4.xy;   // radii of the pair
+                    const f2 ux = {cull.ux, cull.ux}, uy = {cull.uy, cull.uy}, uz = {cull.uz, cull.uz};
+                    const f2 nou = {cull.nou, cull.nou}, ax = {cull.ax, cull.ax}, ay = {cull.ay, cull.ay};
+                    const f2 az = {cull.az, cull.az}, oo = {oo_keep, oo_keep}, tl2 = {tl, tl};
+                    const f2 m = __builtin_elementwise_fma(A.xy, ux, __builtin_elementwise_fma(A.zw, uy, __builtin_elementwise_fma(B.xy, uz, nou)));
+                    const f2 w = __builtin_elementwise_fma(A.xy, ax, __builtin_elementwise_fma(A.zw, ay, __builtin_elementwise_fma(B.xy, az, oo)));
+                    f2 mp;
+                    mp.x = __builtin_fmaxf(m.x, 0.0f); mp.y = __builtin_fmaxf(m.y, 0.0f);
+                    const f2 g = __builtin_elementwise_fma(-mp, mp, w);
+                    const f2 n1 = B.zw - g;             // >= 0: the ray passes within reach sideways
+                    const f2 n2 = (tl2 + rr) - m;       // >= 0: the ball starts before the best hit
+                    // a child survives unless one of the two is negative; collect the sign bits
+                    const float nx = __builtin_fminf(n1.x, n2.x), ny = __builtin_fminf(n1.y, n2.y);
+                    sign_bits |= (__float_as_uint(nx) >> 31) << (2 * pr);
+                    sign_bits |= (__float_as_uint(ny) >> 31) << (2 * pr + 1);
+                    // max(m,0) >= 0 orders like its bit pattern; the low three bits carry the child
+                    // index, a rejected child becomes all ones
+                    const uint32_t kx = ((__float_as_uint(mp.x) & ~7u) | (uint32_t)(2 * pr)) | (uint32_t)((int32_t)__float_as_uint(nx) >> 31);
+                    const uint32_t ky = ((__float_as_uint(mp.y) & ~7u) | (uint32_t)(2 * pr + 1)) | (uint32_t)((int32_t)__float_as_uint(ny) >> 31);
+                    nearest = min(nearest, min(kx, ky));
+                }
+                uint32_t bits = ~sign_bits & 0xffu;
+                if (L == 0u) {
+                    // exact test of the primitives this lane could not reject, in slot order
+                    while (bits != 0u) {
+                        const uint32_t k = (uint32_t)__builtin_ctz(bits);
+                        bits &= bits - 1u;
+                        const uint32_t idx = 8u * st + k;
+                        if (idx < run.count) {
+                            RTK_COUNT(sc, 4, 1);
+                            const uint32_t slot = run.first + idx;
+                            if (KIND == DEV_SPHERE) sphere_exact(sc, slot, (int32_t)sc.sph_id[slot], ray, a, t_min, h, ff_shared);
+                            else tri_exact(sc, slot, (int32_t)sc.tri_id[slot], ray, t_min, h, ff_shared);
+                        }
+                    }
+                }
+                if (L != 0u && bits != 0u) {
+                    // descend into the surviving child whose ball comes first along the ray (so
+                    // that a near hit bounds the rest of the walk early), remember the others
+                    const uint32_t k = nearest & 7u;
+                    L -= 1u;
+                    pend |= (unsigned long long)(bits & ~(1u << k)) << (8u * L);
+                    st = 8u * st + k;
+                } else {
+                    // next pending sibling, of this node or of its nearest ancestor that has one
+                    const unsigned long long rest = pend >> (8u * L);
+                    if (rest == 0ull) {
+                        act = false;
+                    } else {
+                        const uint32_t z = (uint32_t)__builtin_ctzll(rest);
+                        const uint32_t up = z >> 3, k = z & 7u;
+                        L += up;
+                        st = ((st >> (3u * up)) & ~7u) | k;
+                        pend &= ~(1ull << (8u * L + k));
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -272,7 +513,7 @@ __device__ __forceinline__ void cull_step(const SceneView &sc, const Cull &cull,
 // of the final hit is rebuilt afterwards from the same inputs.
 // ----------------------------------------------------------------------
 __device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, float t_min, bool tracing,
-                                          Hit &h) {
+                                          TreeTable &tbl, Hit &h) {
     h.t = __builtin_inff();
     h.kind = -1;
     h.slot = 0;
@@ -284,56 +525,31 @@ __device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, f
     bool have_cull = false;
     RTK_COUNT(sc, 1, 1);
     for (uint32_t r = 0; r < sc.n_runs; ++r) {
-        const u4 run = sc.runs[r];   // {kind, first, count, id0}
-        if (run.x == DEV_SPHERE) {
-            if (run.z < DEV_CULL_MIN_RUN) {
-                for (uint32_t k = 0; k < run.z; ++k)
-                    sphere_exact(sc, run.y + k, (int32_t)(run.w + k), ray, a, t_min, h, ff_shared);
-            } else {
-                // Long runs: eight spheres per step through the conservative rejection
-                // test; only spheres some lane cannot reject reach Sphere::hit proper,
-                // in list order.  The run is padded to a multiple of sixteen with
-                // entries the test always rejects.
-                if (!have_cull) { cull = cull_setup(ray, a, tracing); have_cull = true; }
-                // Two steps of eight spheres per trip, in ping-pong register sets: the
-                // records of the next step are requested BEFORE the current step is
-                // computed, so the scalar-cache / L2 latency of the s_load_dwordx16 pair
-                // overlaps the arithmetic.  Scalar loads return out of order, the only
-                // wait is "all of them"; it is placed right before the next request, when
-                // the awaited data has had a whole step to arrive.
-                const uint32_t n16 = (run.z + DEV_SPHERE_BATCH - 1u) / DEV_SPHERE_BATCH;
-                const RT_CONST_AS f16 *rec = (const RT_CONST_AS f16 *)(sc.sph_cull + run.y);
-                f16 a0 = rec[0], a1 = rec[1];
-                for (uint32_t b = 0; b < n16; ++b) {
-                    asm volatile("; records of the even step have arrived" ::"s"(a0.s0), "s"(a1.s0));
-                    __builtin_amdgcn_sched_barrier(0);
-                    const f16 b0 = rec[4 * b + 2], b1 = rec[4 * b + 3];
-                    __builtin_amdgcn_sched_barrier(0);
-                    cull_step(sc, cull, a0, a1, run, b * DEV_SPHERE_BATCH, ray, a, t_min, h, ff_shared);
-                    asm volatile("; records of the odd step have arrived" ::"s"(b0.s0), "s"(b1.s0));
-                    __builtin_amdgcn_sched_barrier(0);
-                    const uint32_t nb = (b + 1u < n16) ? b + 1u : b;   // the last trip re-reads itself
-                    a0 = rec[4 * nb]; a1 = rec[4 * nb + 1];
-                    __builtin_amdgcn_sched_barrier(0);
-                    cull_step(sc, cull, b0, b1, run, b * DEV_SPHERE_BATCH + 8u, ray, a, t_min, h, ff_shared);
-                }
-            }
-        } else if (run.x == DEV_PLANE) {
+        const RunView run = load_run(sc, r);
+        if (run.mode != RUN_EXACT) {
+            if (!have_cull) { cull = cull_setup(ray, a); have_cull = true; }
+            if (run.mode == RUN_FLAT) scan_flat(sc, run, cull, tracing, ray, a, t_min, h, ff_shared);
+            else if (run.kind == DEV_SPHERE) scan_tree<DEV_SPHERE>(sc, run, cull, tracing, tbl, ray, a, t_min, h, ff_shared);
+            else scan_tree<DEV_TRI>(sc, run, cull, tracing, tbl, ray, a, t_min, h, ff_shared);
+        } else if (run.kind == DEV_SPHERE) {
+            for (uint32_t k = 0; k < run.count; ++k)
+                sphere_exact(sc, run.first + k, (int32_t)(run.id0 + k), ray, a, t_min, h, ff_shared);
+        } else if (run.kind == DEV_PLANE) {
             // Plane::hit, src/geometry/mod.rs:112-130
-            for (uint32_t k = 0; k < run.z; ++k) {
-                const f4 n4 = sc.planes[2 * (run.y + k)];
-                const f4 p4 = sc.planes[2 * (run.y + k) + 1];
+            for (uint32_t k = 0; k < run.count; ++k) {
+                const f4 n4 = sc.planes[2 * (run.first + k)];
+                const f4 p4 = sc.planes[2 * (run.first + k) + 1];
                 V3 n = mk(n4.x, n4.y, n4.z);
                 float t = dot(mk(p4.x, p4.y, p4.z) - ray.o, n) / dot(n, ray.d);
                 if (t < t_min || t > h.t) continue;
-                h.t = t; h.kind = DEV_PLANE; h.slot = run.y + k; h.id = (int32_t)(run.w + k);
+                h.t = t; h.kind = DEV_PLANE; h.slot = run.first + k; h.id = (int32_t)(run.id0 + k);
                 if (sc.need_ff_shared) ff_shared = dot(ray.d, n) < 0.0f;
             }
-        } else if (run.x == DEV_CUBE) {
+        } else if (run.kind == DEV_CUBE) {
             // Cube::hit, src/geometry/mod.rs:158-223
-            for (uint32_t k = 0; k < run.z; ++k) {
-                const f4 c0 = sc.cubes[4 * (run.y + k) + 2];
-                const f4 c1 = sc.cubes[4 * (run.y + k) + 3];
+            for (uint32_t k = 0; k < run.count; ++k) {
+                const f4 c0 = sc.cubes[4 * (run.first + k) + 2];
+                const f4 c1 = sc.cubes[4 * (run.first + k) + 3];
                 float tmin, tmax, tymin, tymax, tzmin, tzmax;
                 if (ray.d.x >= 0.0f) { tmin = (c0.x - ray.o.x) / ray.d.x; tmax = (c1.x - ray.o.x) / ray.d.x; }
                 else                 { tmin = (c1.x - ray.o.x) / ray.d.x; tmax = (c0.x - ray.o.x) / ray.d.x; }
@@ -348,35 +564,13 @@ __device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, f
                 if (tzmin > tmin) tmin = tzmin;
                 if (tzmax < tmax) tmax = tzmax;
                 if (tmin < h.t && tmax > t_min) {
-                    h.t = tmin; h.kind = DEV_CUBE; h.slot = run.y + k; h.id = (int32_t)(run.w + k);
+                    h.t = tmin; h.kind = DEV_CUBE; h.slot = run.first + k; h.id = (int32_t)(run.id0 + k);
                     h.ff = ff_shared;   // no set_face_normal in Cube::hit
                 }
             }
         } else {
-            // Triangle (defined by rt_hip.h, absent from the reference)
-            for (uint32_t k = 0; k < run.z; ++k) {
-                const f4 v0 = sc.tris[3 * (run.y + k)];
-                const f4 e1 = sc.tris[3 * (run.y + k) + 1];
-                const f4 e2 = sc.tris[3 * (run.y + k) + 2];
-                V3 E1 = mk(e1.x, e1.y, e1.z), E2 = mk(e2.x, e2.y, e2.z);
-                V3 hh = cross(ray.d, E2);
-                float det = dot(E1, hh);
-                if (det == 0.0f) continue;
-                float f = 1.0f / det;
-                V3 s = ray.o - mk(v0.x, v0.y, v0.z);
-                float u = f * dot(s, hh);
-                if (u < 0.0f || u > 1.0f) continue;
-                V3 q = cross(s, E1);
-                float v = f * dot(ray.d, q);
-                if (v < 0.0f || u + v > 1.0f) continue;
-                float t = f * dot(E2, q);
-                if (t < t_min || h.t < t) continue;
-                h.t = t; h.kind = DEV_TRI; h.slot = run.y + k; h.id = (int32_t)(run.w + k);
-                if (sc.need_ff_shared) {
-                    V3 outward = unit(cross(E1, E2));
-                    ff_shared = dot(ray.d, outward) < 0.0f;
-                }
-            }
+            for (uint32_t k = 0; k < run.count; ++k)
+                tri_exact(sc, run.first + k, (int32_t)(run.id0 + k), ray, t_min, h, ff_shared);
         }
     }
 }
@@ -542,7 +736,7 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
 
     while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
         Hit h;
-        scan_list(sc, ray, p.t_min, alive, h);
+        scan_list(sc, ray, p.t_min, alive, lds.tree[wave], h);
         n_seg += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(alive));
         if (alive) {
             if (s == 0u && n_stack == 0u) fr.primary_ids[pix_out] = h.id;

@@ -1,0 +1,369 @@
+// rt_scene_build.cpp - turns the structure-of-arrays scene of the C ABI into the
+// device layout the render kernel scans (host side only, no HIP calls).
+//
+// The reference's Vec<Box<dyn Hittable>> (src/geometry/mod.rs:228-238) is cut
+// into maximal runs of one primitive kind, in list order.  A run is scanned in
+// one of three ways:
+//   RUN_EXACT  every primitive gets its hit() arithmetic, in list order;
+//   RUN_FLAT   (spheres) list order, but eight spheres per step first go through
+//              a conservative rejection test on packed FMAs;
+//   RUN_TREE   (spheres, triangles) the run is re-ordered by recursive median
+//              splits and an implicit 8-ary tree of bounding spheres is laid over it; the same
+//              rejection test prunes whole subtrees.  Ties between equal hit
+//              distances are resolved by list position explicitly, so the result
+//              equals the list-order scan.
+#include "rt_scene_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+
+namespace {
+
+inline float bits_to_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+struct Ball { double x, y, z, r; };
+
+// smallest float >= v
+float round_up(double v) {
+    float f = (float)v;
+    if ((double)f < v) f = std::nextafterf(f, INFINITY);
+    return f;
+}
+
+// Rejection record {cx,cy,cz,thr} of the ball (c, r) at margin eps:
+//   thr = r^2 (1+eps) - |c|^2 (1-eps), rounded up; the kernel rejects when
+//   |o|^2 (1-eps) - 2 o.c - ((c-o).u)^2 > thr.
+// Balls whose magnitudes leave the range in which the kernel's error bound holds
+// are never rejected (thr = +inf).
+float4 reject_record(const Ball &b, double eps) {
+    const double c2 = b.x * b.x + b.y * b.y + b.z * b.z;
+    const double r2 = b.r * b.r;
+    float thr = INFINITY;
+    if (c2 < 1e30 && r2 < 1e30 && c2 + r2 > 1e-24 && eps <= 1.0 / 16.0)
+        thr = round_up(r2 * (1.0 + eps) - c2 * (1.0 - eps));
+    return make_float4((float)b.x, (float)b.y, (float)b.z, thr);
+}
+const float4 NEVER_PASS = {0.f, 0.f, 0.f, -INFINITY};   // g > -inf: always rejected
+
+// Slot order for the implicit 8-ary tree: order[k] = index (within the run) of the
+// primitive placed at slot k.  The tree's shape is fixed by the slot numbers alone
+// (eight consecutive slots form a leaf step, eight consecutive steps a node, ...),
+// so the order decides how compact every node is.  Top-down: the slots a node
+// covers are cut into its (up to eight) children's slot ranges by recursive
+// bisection at the median along the longest axis of the centres' bounding box;
+// then each child is arranged the same way.
+struct Arranger {
+    const std::vector<Ball> &balls;
+    std::vector<uint32_t> &idx;
+
+    double coord(uint32_t i, int axis) const { return axis == 0 ? balls[i].x : axis == 1 ? balls[i].y : balls[i].z; }
+
+    // cut idx[a, a+n) into `groups` consecutive chunks of `cap` primitives (the last may be short)
+    void split(size_t a, size_t n, size_t groups, size_t cap) {
+        if (groups <= 1) return;
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t k = a; k < a + n; ++k)
+            for (int ax = 0; ax < 3; ++ax) {
+                const double v = coord(idx[k], ax);
+                if (v < lo[ax]) lo[ax] = v;
+                if (v > hi[ax]) hi[ax] = v;
+            }
+        int axis = 0;
+        if (hi[1] - lo[1] > hi[axis] - lo[axis]) axis = 1;
+        if (hi[2] - lo[2] > hi[axis] - lo[axis]) axis = 2;
+        const size_t gl = groups / 2, left = gl * cap;
+        std::nth_element(idx.begin() + a, idx.begin() + a + left, idx.begin() + a + n, [&](uint32_t p, uint32_t q) {
+            const double u = coord(p, axis), v = coord(q, axis);
+            return u < v || (u == v && p < q);   // total order: NaN-free input assumed, ties by index
+        });
+        split(a, left, gl, cap);
+        split(a + left, n - left, groups - gl, cap);
+    }
+    // arrange idx[a, a+n), whose node's children each cover `cap` primitives
+    void arrange(size_t a, size_t n, size_t cap) {
+        if (n <= 8) return;
+        const size_t groups = (n + cap - 1) / cap;
+        split(a, n, groups, cap);
+        if (cap > 8)
+            for (size_t g = 0; g < groups; ++g) arrange(a + g * cap, std::min(cap, n - g * cap), cap / 8);
+    }
+};
+
+std::vector<uint32_t> tree_order(const std::vector<Ball> &balls) {
+    std::vector<uint32_t> order(balls.size());
+    std::iota(order.begin(), order.end(), 0u);
+    for (const Ball &b : balls)
+        if (!(b.x == b.x && b.y == b.y && b.z == b.z)) return order;   // NaN centres: leave the list order
+    size_t steps = (balls.size() + 7) / 8, cap = 8;
+    while (steps > 8) { steps = (steps + 7) / 8; cap *= 8; }   // cap = primitives under one child of the top node
+    Arranger ar{balls, order};
+    ar.arrange(0, balls.size(), cap);
+    return order;
+}
+
+// pair layout the kernel reads with s_load_dwordx16: two records interleaved as
+// {cx0,cx1, cy0,cy1, cz0,cz1, thr0,thr1}
+void append_paired(std::vector<float4> &out, const std::vector<float4> &recs) {
+    for (size_t k = 0; k + 1 < recs.size(); k += 2) {
+        const float4 a = recs[k], b = recs[k + 1];
+        out.push_back(make_float4(a.x, b.x, a.y, b.y));
+        out.push_back(make_float4(a.z, b.z, a.w, b.w));
+    }
+}
+
+// Tree layout of one step (eight balls, 160 bytes): the x,y of the four pairs,
+// the z,thr of the four pairs, then the eight radii (rounded up) for the
+// "beyond the best hit" test.
+void append_tree_step(std::vector<float4> &out, const float4 *recs, const float *radii) {
+    for (int p = 0; p < 4; ++p) out.push_back(make_float4(recs[2 * p].x, recs[2 * p + 1].x, recs[2 * p].y, recs[2 * p + 1].y));
+    for (int p = 0; p < 4; ++p) out.push_back(make_float4(recs[2 * p].z, recs[2 * p + 1].z, recs[2 * p].w, recs[2 * p + 1].w));
+    out.push_back(make_float4(radii[0], radii[1], radii[2], radii[3]));
+    out.push_back(make_float4(radii[4], radii[5], radii[6], radii[7]));
+}
+
+// Builds the levels of the implicit 8-ary tree over `leaves` (already in sorted
+// order) and appends their records to scene.cull_rec.  leaf_eps is the margin of
+// level 0; rho[k] is the radius that scales the guard band of leaf k (its own
+// radius).  Level L >= 1 holds one ball per 8-record step of level L-1; a ball's
+// margin is leaf_eps * 2^j with 2^j >= 2 * (its radius / the smallest rho below
+// it): a ray that clears the ball by that margin clears every leaf below it by
+// the leaf's own margin (a near miss of the ball at a point where a small leaf
+// touches it from inside is the binding case).  That scaling is what spheres
+// need, because the f32 discriminant of Sphere::hit is uncertain by an amount
+// that does not shrink with the sphere (about 20 ulp of |o-c|^2).  The f32
+// triangle test is uncertain by a DISTANCE of a few ulp of |o-v0| whatever the
+// triangle's size, which one constant margin covers at every level
+// (scale_with_ratio = false).
+void build_tree(HostScene &sc, DevRun &run, const std::vector<Ball> &leaves, double leaf_eps,
+                bool scale_with_ratio) {
+    struct Node { Ball b; double rho_min; };
+    std::vector<Node> cur(leaves.size());
+    for (size_t k = 0; k < leaves.size(); ++k) cur[k] = {leaves[k], std::abs(leaves[k].r)};
+    uint32_t level = 0;
+    double eps = leaf_eps;
+    for (;;) {
+        // emit this level, padded to whole steps of 8 records
+        std::vector<float4> recs;
+        std::vector<float> radii;
+        recs.reserve((cur.size() + 7) / 8 * 8);
+        for (const Node &n : cur) {
+            float4 rec = reject_record(n.b, eps);
+            if (rec.w == 0.0f) rec.w = 0.0f;   // no negative zero: the kernel reads sign bits
+            recs.push_back(rec);
+            radii.push_back(round_up(std::abs(n.b.r) * (1.0 + 1e-6)));
+            const double reach = std::sqrt(n.b.x * n.b.x + n.b.y * n.b.y + n.b.z * n.b.z) + std::abs(n.b.r);
+            if (reach < 1e30) run.reach = std::max(run.reach, round_up(reach));
+        }
+        while (recs.size() % 8) { recs.push_back(NEVER_PASS); radii.push_back(0.0f); }
+        run.level_base[level] = (uint32_t)(sc.tree_rec.size() / 10);   // in steps (10 float4 each)
+        run.level_keep[level] = (float)(1.0 - eps);
+        for (size_t k = 0; k < recs.size(); k += 8) append_tree_step(sc.tree_rec, &recs[k], &radii[k]);
+        const size_t n_steps = recs.size() / 8;
+        if (n_steps == 1 || level + 1 == DEV_MAX_LEVELS) {
+            run.n_levels = level + 1;
+            run.top_steps = (uint32_t)n_steps;
+            return;
+        }
+        // next level: one ball around each step
+        std::vector<Node> up(n_steps);
+        double max_ratio = 1.0;
+        for (size_t s = 0; s < n_steps; ++s) {
+            const size_t b0 = s * 8, b1 = std::min(cur.size(), b0 + 8);
+            double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            double rho_min = INFINITY;
+            for (size_t k = b0; k < b1; ++k) {
+                const Ball &c = cur[k].b;
+                const double p[3] = {c.x, c.y, c.z};
+                const double r = std::abs(c.r);
+                for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[a] - r); hi[a] = std::max(hi[a], p[a] + r); }
+                rho_min = std::min(rho_min, cur[k].rho_min);
+            }
+            Ball m{(lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, (lo[2] + hi[2]) / 2, 0.0};
+            // the float centre the kernel sees is what distances are measured from
+            m.x = (float)m.x; m.y = (float)m.y; m.z = (float)m.z;
+            for (size_t k = b0; k < b1; ++k) {
+                const Ball &c = cur[k].b;
+                const double d = std::sqrt((c.x - m.x) * (c.x - m.x) + (c.y - m.y) * (c.y - m.y) + (c.z - m.z) * (c.z - m.z));
+                m.r = std::max(m.r, d + std::abs(c.r));
+            }
+            m.r *= 1.0 + 1e-6;
+            if (!(m.r == m.r)) m.r = INFINITY;   // NaN input: never rejected
+            up[s] = {m, rho_min};
+            if (rho_min > 0 && m.r < INFINITY) max_ratio = std::max(max_ratio, m.r / rho_min);
+            else max_ratio = INFINITY;
+        }
+        if (scale_with_ratio) {
+            int j = 1;
+            while (std::ldexp(1.0, j) < 2.0 * max_ratio && j < 40) ++j;
+            eps = leaf_eps * std::ldexp(1.0, j);
+        }
+        // a level whose margin would exceed 1/16 rejects nothing (reject_record caps it)
+        cur.swap(up);
+        ++level;
+    }
+}
+
+}  // namespace
+
+int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::string &err) {
+    const uint64_t n64 = (uint64_t)s->n_spheres + s->n_planes + s->n_cubes + s->n_tris;
+    if (n64 > 0x7fffffffu) { err = "too many primitives"; return RT_E_BADARG; }
+    const uint32_t n = (uint32_t)n64;
+    if ((s->n_spheres && !(s->sph_cx && s->sph_cy && s->sph_cz && s->sph_r && s->sph_mat && s->sph_id)) ||
+        (s->n_planes && !(s->pl_nx && s->pl_ny && s->pl_nz && s->pl_px && s->pl_py && s->pl_pz && s->pl_mat && s->pl_id)) ||
+        (s->n_cubes && !(s->cb_cx && s->cb_cy && s->cb_cz && s->cb_w && s->cb_h && s->cb_d && s->cb_mat && s->cb_id)) ||
+        (s->n_tris && !(s->tri_v0x && s->tri_v0y && s->tri_v0z && s->tri_v1x && s->tri_v1y && s->tri_v1z &&
+                        s->tri_v2x && s->tri_v2y && s->tri_v2z && s->tri_mat && s->tri_id)) ||
+        (s->n_materials && !(s->mat_kind && s->mat_r && s->mat_g && s->mat_b && s->mat_param))) {
+        err = "null array in a non-empty group";
+        return RT_E_BADARG;
+    }
+    if (n > 0 && s->n_materials == 0) { err = "primitives but no materials"; return RT_E_BADARG; }
+    for (uint32_t m = 0; m < s->n_materials; ++m)
+        if (s->mat_kind[m] < RT_METAL || s->mat_kind[m] > RT_DIELECTRIC) { err = "unknown material kind"; return RT_E_BADARG; }
+
+    // list order: the ids of all groups must be a permutation of 0..n-1
+    struct Entry { int kind = -1; uint32_t k = 0; };
+    std::vector<Entry> list(n);
+    auto place = [&](uint32_t id, uint32_t mat, int kind, uint32_t k) -> bool {
+        if (id >= n || list[id].kind != -1 || mat >= s->n_materials) return false;
+        list[id].kind = kind; list[id].k = k;
+        return true;
+    };
+    bool ok = true;
+    for (uint32_t k = 0; ok && k < s->n_spheres; ++k) ok = place(s->sph_id[k], s->sph_mat[k], DEV_SPHERE, k);
+    for (uint32_t k = 0; ok && k < s->n_planes; ++k) ok = place(s->pl_id[k], s->pl_mat[k], DEV_PLANE, k);
+    for (uint32_t k = 0; ok && k < s->n_cubes; ++k) ok = place(s->cb_id[k], s->cb_mat[k], DEV_CUBE, k);
+    for (uint32_t k = 0; ok && k < s->n_tris; ++k) ok = place(s->tri_id[k], s->tri_mat[k], DEV_TRI, k);
+    if (!ok) { err = "ids are not a permutation of the list, or a material index is out of range"; return RT_E_BADARG; }
+
+    for (uint32_t m = 0; m < s->n_materials; ++m) {
+        sc.mat_albedo.push_back(make_float4(s->mat_r[m], s->mat_g[m], s->mat_b[m], s->mat_param[m]));
+        sc.mat_kind.push_back(s->mat_kind[m]);
+    }
+
+    const double LEAF_EPS_SPHERE = 1.0 / 65536.0;   // proven bound of the kernel's test, see cull_pair
+    const double LEAF_EPS_TRI = 1.0 / 4096.0;       // guard band of triangle balls, all levels
+
+    for (uint32_t id = 0; id < n;) {
+        const int kind = list[id].kind;
+        uint32_t end = id;
+        while (end < n && list[end].kind == kind) ++end;
+        const uint32_t count = end - id;
+        DevRun run{};
+        run.kind = (uint32_t)kind;
+        run.count = count;
+        run.id0 = id;
+        run.mode = RUN_EXACT;
+
+        if (kind == DEV_SPHERE) {
+            run.first = (uint32_t)sc.sph_geom.size();
+            std::vector<uint32_t> order(count);
+            std::iota(order.begin(), order.end(), 0u);
+            std::vector<Ball> balls(count);
+            for (uint32_t k = 0; k < count; ++k) {
+                const uint32_t src = list[id + k].k;
+                balls[k] = {s->sph_cx[src], s->sph_cy[src], s->sph_cz[src], s->sph_r[src]};
+            }
+            if (count >= DEV_TREE_MIN_RUN && use_tree) {
+                run.mode = RUN_TREE;
+                order = tree_order(balls);
+            } else if (count >= DEV_CULL_MIN_RUN) {
+                run.mode = RUN_FLAT;
+            }
+            std::vector<Ball> sorted(count);
+            run.order_base = (uint32_t)sc.order.size();
+            sc.order.resize(sc.order.size() + count);
+            for (uint32_t k = 0; k < count; ++k) {
+                const uint32_t src = list[id + order[k]].k;
+                sorted[k] = balls[order[k]];
+                sc.sph_geom.push_back(make_float4(s->sph_cx[src], s->sph_cy[src], s->sph_cz[src], s->sph_r[src]));
+                sc.sph_mat.push_back(s->sph_mat[src]);
+                sc.sph_id.push_back(id + order[k]);
+                sc.order[run.order_base + order[k]] = k;   // list position within the run -> slot offset
+            }
+            if (run.mode == RUN_TREE) {
+                build_tree(sc, run, sorted, LEAF_EPS_SPHERE, true);
+            } else if (run.mode == RUN_FLAT) {
+                std::vector<float4> recs;
+                for (const Ball &b : sorted) recs.push_back(reject_record(b, LEAF_EPS_SPHERE));
+                while (recs.size() % 16) recs.push_back(NEVER_PASS);   // two steps per loop trip
+                run.level_base[0] = (uint32_t)(sc.cull_rec.size() / 8);
+                run.level_keep[0] = (float)(1.0 - LEAF_EPS_SPHERE);
+                run.n_levels = 1;
+                run.top_steps = (uint32_t)(recs.size() / 8);
+                append_paired(sc.cull_rec, recs);
+            }
+        } else if (kind == DEV_PLANE) {
+            run.first = (uint32_t)(sc.planes.size() / 2);
+            for (uint32_t k = 0; k < count; ++k) {
+                const uint32_t src = list[id + k].k;
+                sc.planes.push_back(make_float4(s->pl_nx[src], s->pl_ny[src], s->pl_nz[src], bits_to_float(s->pl_mat[src])));
+                sc.planes.push_back(make_float4(s->pl_px[src], s->pl_py[src], s->pl_pz[src], 0.f));
+            }
+        } else if (kind == DEV_CUBE) {
+            run.first = (uint32_t)(sc.cubes.size() / 4);
+            for (uint32_t k = 0; k < count; ++k) {
+                const uint32_t src = list[id + k].k;
+                // Cube::new, src/geometry/mod.rs:146-154: corners from center and extents;
+                // w/2 is also what Cube::hit divides by (:213-215)
+                const float cx = s->cb_cx[src], cy = s->cb_cy[src], cz = s->cb_cz[src];
+                const float w = s->cb_w[src], h = s->cb_h[src], d = s->cb_d[src];
+                const float hw = w / 2.0f, hh = h / 2.0f, hd = d / 2.0f;
+                const float c0x = cx + (-w / 2.0f), c0y = cy + (-h / 2.0f), c0z = cz + (-d / 2.0f);
+                const float c1x = cx + hw, c1y = cy + hh, c1z = cz + hd;
+                sc.cubes.push_back(make_float4(cx, cy, cz, bits_to_float(s->cb_mat[src])));
+                sc.cubes.push_back(make_float4(hw, hh, hd, 0.f));
+                sc.cubes.push_back(make_float4(c0x, c0y, c0z, 0.f));
+                sc.cubes.push_back(make_float4(c1x, c1y, c1z, 0.f));
+                if (s->mat_kind[s->cb_mat[src]] == RT_DIELECTRIC) sc.need_ff_shared = 1;
+            }
+        } else {
+            run.first = (uint32_t)(sc.tris.size() / 3);
+            std::vector<uint32_t> order(count);
+            std::iota(order.begin(), order.end(), 0u);
+            std::vector<Ball> balls(count);
+            for (uint32_t k = 0; k < count; ++k) {
+                const uint32_t src = list[id + k].k;
+                const double v[3][3] = {{s->tri_v0x[src], s->tri_v0y[src], s->tri_v0z[src]},
+                                        {s->tri_v1x[src], s->tri_v1y[src], s->tri_v1z[src]},
+                                        {s->tri_v2x[src], s->tri_v2y[src], s->tri_v2z[src]}};
+                Ball b{(v[0][0] + v[1][0] + v[2][0]) / 3, (v[0][1] + v[1][1] + v[2][1]) / 3,
+                       (v[0][2] + v[1][2] + v[2][2]) / 3, 0.0};
+                b.x = (float)b.x; b.y = (float)b.y; b.z = (float)b.z;
+                for (int i = 0; i < 3; ++i)
+                    b.r = std::max(b.r, std::sqrt((v[i][0] - b.x) * (v[i][0] - b.x) + (v[i][1] - b.y) * (v[i][1] - b.y) +
+                                                  (v[i][2] - b.z) * (v[i][2] - b.z)));
+                b.r *= 1.0 + 1e-3;
+                if (!(b.r == b.r)) b.r = INFINITY;
+                balls[k] = b;
+            }
+            if (count >= DEV_TREE_MIN_RUN && use_tree) {
+                run.mode = RUN_TREE;
+                order = tree_order(balls);
+            }
+            std::vector<Ball> sorted(count);
+            run.order_base = (uint32_t)sc.order.size();
+            sc.order.resize(sc.order.size() + count);
+            for (uint32_t k = 0; k < count; ++k) {
+                const uint32_t src = list[id + order[k]].k;
+                sorted[k] = balls[order[k]];
+                const float ax = s->tri_v0x[src], ay = s->tri_v0y[src], az = s->tri_v0z[src];
+                const float e1x = s->tri_v1x[src] - ax, e1y = s->tri_v1y[src] - ay, e1z = s->tri_v1z[src] - az;
+                const float e2x = s->tri_v2x[src] - ax, e2y = s->tri_v2y[src] - ay, e2z = s->tri_v2z[src] - az;
+                sc.tris.push_back(make_float4(ax, ay, az, bits_to_float(s->tri_mat[src])));
+                sc.tris.push_back(make_float4(e1x, e1y, e1z, 0.f));
+                sc.tris.push_back(make_float4(e2x, e2y, e2z, 0.f));
+                sc.tri_id.push_back(id + order[k]);
+                sc.order[run.order_base + order[k]] = k;
+            }
+            if (run.mode == RUN_TREE) build_tree(sc, run, sorted, LEAF_EPS_TRI, false);
+        }
+        sc.runs.push_back(run);
+        id = end;
+    }
+    return RT_OK;
+}

@@ -1,0 +1,29 @@
+// rt_scene_build.h - host-side construction of the device scene layout.
+#ifndef RT_SCENE_BUILD_H
+#define RT_SCENE_BUILD_H
+
+#include <string>
+#include <vector>
+
+#include "rt_device.h"
+
+struct HostScene {
+    std::vector<DevRun> runs;
+    std::vector<float4> sph_geom;     // cx, cy, cz, radius              (slot order)
+    std::vector<uint32_t> sph_mat, sph_id;
+    std::vector<float4> planes, cubes, tris;
+    std::vector<uint32_t> tri_id;
+    std::vector<float4> cull_rec;     // RUN_FLAT rejection records, 8 float4 per step
+    std::vector<float4> tree_rec;     // RUN_TREE records, 10 float4 per step
+    std::vector<uint32_t> order;      // per tree/flat run: list position -> slot offset
+    std::vector<float4> mat_albedo;
+    std::vector<int32_t> mat_kind;
+    uint32_t need_ff_shared = 0;
+};
+
+// Validates `s` and fills `out`.  use_tree = false keeps long runs in list order
+// (RUN_FLAT for spheres, RUN_EXACT for triangles).  Returns RT_OK or RT_E_BADARG
+// with a message in err.
+int build_host_scene(const rt_scene *s, bool use_tree, HostScene &out, std::string &err);
+
+#endif
