@@ -184,6 +184,9 @@ int rt_upload_scene(rt_ctx *ctx, const rt_scene *s) {
     DevScene d{};
     d.n_runs = (uint32_t)hs.runs.size();
     d.need_ff_shared = hs.need_ff_shared;
+    d.lds_run = hs.lds_run; d.lds_level = hs.lds_level;
+    d.lds_first_step = hs.lds_first_step; d.lds_steps = hs.lds_steps;
+    d.modes = hs.modes;
     if ((rc = upload(c, hs.runs, &d.runs)) != RT_OK || (rc = upload(c, hs.sph_geom, &d.sph_geom)) != RT_OK ||
         (rc = upload(c, hs.sph_mat, &d.sph_mat)) != RT_OK || (rc = upload(c, hs.sph_id, &d.sph_id)) != RT_OK ||
         (rc = upload(c, hs.planes, &d.planes)) != RT_OK || (rc = upload(c, hs.cubes, &d.cubes)) != RT_OK ||

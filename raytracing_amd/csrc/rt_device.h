@@ -60,7 +60,12 @@ struct DevScene {
     const uint32_t *order;    // see DevRun::order_base
     const float4 *mat_albedo; // r, g, b, param
     const int32_t *mat_kind;
+    // the top levels of ONE tree run are copied into LDS by every workgroup:
+    // levels >= lds_level of run lds_run, tree_rec steps [lds_first_step, +lds_steps)
+    uint32_t lds_run, lds_level, lds_first_step, lds_steps;
+    uint32_t modes;           // bit 0: some run is RUN_FLAT, bit 1: some run is RUN_TREE
 };
+#define DEV_TREE_LDS_STEPS 192u   // 30 KB of tree per workgroup
 
 // Per-frame buffers and the lookup tables
 struct DevFrame {

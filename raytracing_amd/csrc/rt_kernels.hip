@@ -18,6 +18,10 @@
 
 #include "rt_device.h"
 
+#ifndef RTK_TREE_WAVES
+#define RTK_TREE_WAVES 8
+#endif
+
 namespace rtk {
 
 // ------------------------------------------------------------------ vec3
@@ -85,6 +89,7 @@ struct SceneView {
     const RT_CONST_AS uint32_t *sph_mat, *sph_id, *tri_id, *order;
     const RT_CONST_AS int32_t *mat_kind;
     uint32_t n_runs, need_ff_shared;
+    uint32_t lds_run, lds_level, lds_first_step;
     unsigned long long *stats;   // fr.segments; slots 1..7 are instrumentation (RTK_STATS builds)
 };
 __device__ __forceinline__ SceneView view_of(const DevScene &sc, unsigned long long *stats) {
@@ -105,6 +110,7 @@ __device__ __forceinline__ SceneView view_of(const DevScene &sc, unsigned long l
     v.mat_kind = const_ptr<int32_t>(sc.mat_kind);
     v.n_runs = sc.n_runs;
     v.need_ff_shared = sc.need_ff_shared;
+    v.lds_run = sc.lds_run; v.lds_level = sc.lds_level; v.lds_first_step = sc.lds_first_step;
     return v;
 }
 // the words of a DevRun as the two scalar loads deliver them
@@ -123,16 +129,22 @@ __device__ __forceinline__ RunView load_run(const SceneView &sc, uint32_t r) {
     return v;
 }
 
-constexpr int WAVES_PER_BLOCK = 4;
+// wavefronts per workgroup: 8 when a tree copy in LDS is shared, else 4
+__host__ __device__ constexpr int waves_of(int modes) { return (modes & 2) ? RTK_TREE_WAVES : 4; }
 constexpr int TILE = 8;   // 8x8 pixels per wavefront
 
 struct TreeTable { uint32_t base[DEV_MAX_LEVELS]; float keep[DEV_MAX_LEVELS]; };
 
+// MODES: bit 0 = the scene has RUN_FLAT runs, bit 1 = it has RUN_TREE runs; the
+// kernel is compiled once per combination so that scenes without a tree do not
+// pay registers and LDS for it
+template <int MODES>
 struct Lds {
     float disc[128];                                    // src/denoising/mod.rs:55
     float sphere[768];                                  // src/denoising/mod.rs:59
-    uint32_t mat_stack[WAVES_PER_BLOCK][RT_MAX_BOUNCES][64];
-    TreeTable tree[WAVES_PER_BLOCK];                    // per-level constants of the run being walked
+    uint32_t mat_stack[waves_of(MODES)][RT_MAX_BOUNCES][64];
+    TreeTable tree[waves_of(MODES)];                    // per-level constants of the run being walked
+    f4 tree_top[(MODES & 2) ? DEV_TREE_LDS_STEPS * 10 : 1];   // top levels of one tree (DevScene::lds_*)
 };
 
 struct Ray { V3 o, d; };
@@ -154,9 +166,9 @@ __device__ __forceinline__ Ray get_ray(const rt_camera &c, float s, float t, flo
 }
 
 // BlueNoise::random_in_unit_sphere, src/denoising/mod.rs:37-50: (v*sp_bn)*1.1
-__device__ __forceinline__ V3 rius(const Lds &lds, uint32_t seed, float sp_bn) {
+__device__ __forceinline__ V3 rius(const float *tbl_sphere, uint32_t seed, float sp_bn) {
     uint32_t k = seed & 255u;
-    V3 t = mk(lds.sphere[3 * k], lds.sphere[3 * k + 1], lds.sphere[3 * k + 2]);
+    V3 t = mk(tbl_sphere[3 * k], tbl_sphere[3 * k + 1], tbl_sphere[3 * k + 2]);
     return (t * sp_bn) * 1.1f;
 }
 
@@ -398,8 +410,8 @@ __device__ __forceinline__ void scan_flat(const SceneView &sc, const RunView &ru
 // ----------------------------------------------------------------------
 template <int KIND>
 __device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &run, const Cull &cull, bool tracing,
-                                          TreeTable &tbl, const Ray &ray, float a, float t_min, Hit &h,
-                                          bool &ff_shared) {
+                                          TreeTable &tbl, const f4 *tree_top, uint32_t lds_from_level,
+                                          const Ray &ray, float a, float t_min, Hit &h, bool &ff_shared) {
     const float big = 1e18f;
     const bool tame = a > 0.0f && a < big && h.t == h.t &&
                       __builtin_fabsf(ray.o.x) < big && __builtin_fabsf(ray.o.y) < big && __builtin_fabsf(ray.o.z) < big;
@@ -435,7 +447,19 @@ __device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &ru
             RTK_COUNT(sc, 5, __builtin_popcountll(__builtin_amdgcn_ballot_w64(act)));
             RTK_COUNT(sc, 6, __builtin_popcountll(__builtin_amdgcn_ballot_w64(act && L == 0u)));
             if (act) {
-                const RT_CONST_AS f4 *nd = nodes + 10u * (size_t)(tbl.base[L] + st);
+                // the node's 160 bytes: from the workgroup's LDS copy for the top levels of the
+                // cached tree, from global memory (L1/L2) otherwise
+                const uint32_t step = tbl.base[L] + st;
+                f4 nd[10];
+                if (L >= lds_from_level) {
+                    const f4 *src = tree_top + 10u * (step - sc.lds_first_step);
+#pragma unroll
+                    for (int q = 0; q < 10; ++q) nd[q] = src[q];
+                } else {
+                    const RT_CONST_AS f4 *src = nodes + 10u * (size_t)step;
+#pragma unroll
+                    for (int q = 0; q < 10; ++q) nd[q] = src[q];
+                }
                 const float oo_keep = cull.oo * tbl.keep[L];
                 const float tl = __builtin_fmaf(h.t, far_len, far_pad);   // inf while nothing is hit
                 uint32_t sign_bits = 0u;
@@ -512,8 +536,9 @@ __device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &ru
 // reference, so only (t, primitive, front_face) is tracked here and the record
 // of the final hit is rebuilt afterwards from the same inputs.
 // ----------------------------------------------------------------------
+template <int MODES>
 __device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, float t_min, bool tracing,
-                                          TreeTable &tbl, Hit &h) {
+                                          TreeTable &tbl, const f4 *tree_top, Hit &h) {
     h.t = __builtin_inff();
     h.kind = -1;
     h.slot = 0;
@@ -526,11 +551,15 @@ __device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, f
     RTK_COUNT(sc, 1, 1);
     for (uint32_t r = 0; r < sc.n_runs; ++r) {
         const RunView run = load_run(sc, r);
-        if (run.mode != RUN_EXACT) {
+        if (MODES != 0 && run.mode != RUN_EXACT) {
             if (!have_cull) { cull = cull_setup(ray, a); have_cull = true; }
-            if (run.mode == RUN_FLAT) scan_flat(sc, run, cull, tracing, ray, a, t_min, h, ff_shared);
-            else if (run.kind == DEV_SPHERE) scan_tree<DEV_SPHERE>(sc, run, cull, tracing, tbl, ray, a, t_min, h, ff_shared);
-            else scan_tree<DEV_TRI>(sc, run, cull, tracing, tbl, ray, a, t_min, h, ff_shared);
+            // levels >= from are read from the LDS copy (only the cached run has any)
+            const uint32_t from = (r == sc.lds_run) ? sc.lds_level : 0xffffffffu;
+            if ((MODES & 1) && run.mode == RUN_FLAT) scan_flat(sc, run, cull, tracing, ray, a, t_min, h, ff_shared);
+            else if ((MODES & 2) && run.kind == DEV_SPHERE)
+                scan_tree<DEV_SPHERE>(sc, run, cull, tracing, tbl, tree_top, from, ray, a, t_min, h, ff_shared);
+            else if (MODES & 2)
+                scan_tree<DEV_TRI>(sc, run, cull, tracing, tbl, tree_top, from, ray, a, t_min, h, ff_shared);
         } else if (run.kind == DEV_SPHERE) {
             for (uint32_t k = 0; k < run.count; ++k)
                 sphere_exact(sc, run.first + k, (int32_t)(run.id0 + k), ray, a, t_min, h, ff_shared);
@@ -578,7 +607,7 @@ __device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, f
 // Rebuild the HitRecord of the closest hit (p, normal, front_face) exactly as
 // the primitive's hit() filled it, then run its material's scatter.
 // Returns the material index; ray is replaced by the scattered ray.
-__device__ __forceinline__ uint32_t shade_hit(const SceneView &sc, const Lds &lds, Ray &ray, const Hit &h,
+__device__ __forceinline__ uint32_t shade_hit(const SceneView &sc, const float *tbl_sphere, Ray &ray, const Hit &h,
                                               float sp_bn, uint32_t &path_counter, uint32_t path_key,
                                               uint32_t bounce) {
     V3 p = ray.o + ray.d * h.t;   // Ray::at, src/ray/mod.rs:19-21
@@ -627,11 +656,11 @@ __device__ __forceinline__ uint32_t shade_hit(const SceneView &sc, const Lds &ld
         // Metal::scatter, src/geometry/mod.rs:274-281
         V3 reflected = reflect(unit(ray.d), normal);
         path_counter += 1;
-        dir = reflected + rius(lds, path_counter, sp_bn) * ma.w;
+        dir = reflected + rius(tbl_sphere, path_counter, sp_bn) * ma.w;
     } else if (mk_ == RT_LAMBERTIAN) {
         // Lambertian::scatter, src/geometry/mod.rs:287-299
         path_counter += 1;
-        dir = normal + rius(lds, path_counter, sp_bn);
+        dir = normal + rius(tbl_sphere, path_counter, sp_bn);
         if (dir.x < 0.0f && dir.y < 0.0f && dir.z < 0.0f) dir = normal;   // is_near_zero, src/vector/mod.rs:29-32
     } else {
         // Dielectric::scatter, src/geometry/mod.rs:323-346
@@ -675,21 +704,26 @@ __device__ __forceinline__ V3 sky(V3 d, bool gamma) {
 
 // ----------------------------------------------------------------------
 // calculate_some_pxls + ray_colour, src/raytracer.rs:232-271 and :68-92.
-// grid.x = ceil(W / 32) (four 8x8 tiles side by side per workgroup),
+// grid.x = ceil(W / (8 * waves per workgroup)): the workgroup's 8x8 tiles lie side by side,
 // grid.y = number of 8-row bands this call renders.
 // ----------------------------------------------------------------------
-__global__ __launch_bounds__(WAVES_PER_BLOCK * 64)
+template <int MODES>
+__global__ __launch_bounds__(waves_of(MODES) * 64, 4)   // at most 128 VGPRs: four waves per SIMD
 void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
-    __shared__ Lds lds;
+    __shared__ Lds<MODES> lds;
     const SceneView sc = view_of(dsc, fr.segments);
     for (uint32_t k = threadIdx.x; k < 128; k += blockDim.x) lds.disc[k] = fr.tbl_disc[k];
     for (uint32_t k = threadIdx.x; k < 768; k += blockDim.x) lds.sphere[k] = fr.tbl_sphere[k];
+    if (MODES & 2) {
+        const RT_CONST_AS f4 *src = sc.tree_rec + 10u * (size_t)dsc.lds_first_step;
+        for (uint32_t k = threadIdx.x; k < dsc.lds_steps * 10u; k += blockDim.x) lds.tree_top[k] = src[k];
+    }
     __syncthreads();
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t W = p.width, H = p.height;
     const uint32_t band = p.band_begin + blockIdx.y * p.band_stride;
-    const uint32_t i = (blockIdx.x * WAVES_PER_BLOCK + wave) * TILE + (lane & 7u);   // column
+    const uint32_t i = (blockIdx.x * waves_of(MODES) + wave) * TILE + (lane & 7u);     // column
     const uint32_t j = band * TILE + (lane >> 3);                                    // row from the bottom
     const bool inside = i < W && j < H;
     const uint32_t row = H - 1u - j;                                                 // src/raytracer.rs:265
@@ -736,7 +770,7 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
 
     while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
         Hit h;
-        scan_list(sc, ray, p.t_min, alive, lds.tree[wave], h);
+        scan_list<MODES>(sc, ray, p.t_min, alive, lds.tree[wave], lds.tree_top, h);
         n_seg += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(alive));
         if (alive) {
             if (s == 0u && n_stack == 0u) fr.primary_ids[pix_out] = h.id;
@@ -744,7 +778,7 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
             V3 c;
             if (h.kind >= 0) {
                 uint32_t bounce = p.max_bounces - depth_left;
-                uint32_t mat = shade_hit(sc, lds, ray, h, sp_bn, path_counter, path_key, bounce);
+                uint32_t mat = shade_hit(sc, lds.sphere, ray, h, sp_bn, path_counter, path_key, bounce);
                 lds.mat_stack[wave][n_stack][lane] = mat;
                 n_stack += 1;
                 depth_left -= 1;
@@ -825,8 +859,15 @@ hipError_t rtk_launch_pack_bands(const float4 *accum, uint32_t *out, uint32_t W,
 }
 hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_params &p,
                              const DevFrame &fr, uint32_t n_bands, hipStream_t stream) {
-    dim3 grid((p.width + 31u) / 32u, n_bands, 1), block(rtk::WAVES_PER_BLOCK * 64, 1, 1);
-    hipLaunchKernelGGL(rtk::render_tiles, grid, block, 0, stream, sc, cam, p, fr);
+    const uint32_t waves = (uint32_t)rtk::waves_of((int)(sc.modes & 3u));
+    const uint32_t tile_w = waves * rtk::TILE;
+    dim3 grid((p.width + tile_w - 1u) / tile_w, n_bands, 1), block(waves * 64, 1, 1);
+    switch (sc.modes & 3u) {
+    case 0: hipLaunchKernelGGL(rtk::render_tiles<0>, grid, block, 0, stream, sc, cam, p, fr); break;
+    case 1: hipLaunchKernelGGL(rtk::render_tiles<1>, grid, block, 0, stream, sc, cam, p, fr); break;
+    case 2: hipLaunchKernelGGL(rtk::render_tiles<2>, grid, block, 0, stream, sc, cam, p, fr); break;
+    default: hipLaunchKernelGGL(rtk::render_tiles<3>, grid, block, 0, stream, sc, cam, p, fr); break;
+    }
     return hipGetLastError();
 }
 hipError_t rtk_launch_pack(const float4 *accum, uint32_t *out, uint32_t n_px, hipStream_t stream) {

@@ -365,5 +365,25 @@ int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::strin
         sc.runs.push_back(run);
         id = end;
     }
+    // Which tree keeps its top levels in LDS: the largest one; as many levels from
+    // the top as fit.  A tree's levels are laid out bottom-up, so levels >= L are the
+    // contiguous tail [level_base[L], level_base[top] + top_steps).
+    uint32_t best = 0;
+    for (uint32_t r = 0; r < sc.runs.size(); ++r) {
+        const DevRun &run = sc.runs[r];
+        if (run.mode == RUN_FLAT) sc.modes |= 1u;
+        if (run.mode != RUN_TREE) continue;
+        sc.modes |= 2u;
+        if (run.count <= best) continue;
+        best = run.count;
+        const uint32_t top = run.n_levels - 1u;
+        const uint32_t end_step = run.level_base[top] + run.top_steps;
+        uint32_t L = top;
+        while (L > 0 && end_step - run.level_base[L - 1] <= DEV_TREE_LDS_STEPS) --L;
+        if (end_step - run.level_base[L] > DEV_TREE_LDS_STEPS) continue;   // even the top level alone is too big
+        sc.lds_run = r; sc.lds_level = L;
+        sc.lds_first_step = run.level_base[L];
+        sc.lds_steps = end_step - run.level_base[L];
+    }
     return RT_OK;
 }
