@@ -69,6 +69,45 @@ def cpu_baseline(wl, tables, budget_s=15.0):
     }
 
 
+def flat_scan_probe(r, wl, flops_seg):
+    """The same frame through the list-order scan (RT_HIP_FLAT_SCAN=1: every sphere of the
+    list is tested for every segment, eight per step through the packed-FMA rejection
+    test, exactly the work the reference's linear scan does): 2 spp, timed with HIP events."""
+    from raytracing_amd import make_params
+    w, h, spp = wl["width"], wl["height"], wl["spp"]
+    os.environ["RT_HIP_FLAT_SCAN"] = "1"
+    try:
+        r.set_scene(wl["flat"])
+    finally:
+        del os.environ["RT_HIP_FLAT_SCAN"]
+    r.begin_frame(w, h)
+    r.render(make_params(w, h, spp=spp, sample_begin=0, sample_count=1))   # warm-up
+    r.sync()
+    seg0 = r.ray_count()
+    r.timer_start()
+    r.render(make_params(w, h, spp=spp, sample_begin=1, sample_count=8))
+    ms = r.timer_stop()
+    seg = r.ray_count() - seg0
+    r.set_scene(wl["flat"])
+    achieved = flops_seg * seg / (ms * 1e-3) / 1e12
+    return {"kernel": "render_tiles<1>", "kernel_ms": round(ms, 3), "mrays_per_s": round(seg / ms / 1e3, 3),
+            "achieved": round(achieved, 3), "unit": "TFLOP/s", "peak": PEAK_FP32_VECTOR_TFLOPS,
+            "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4),
+            "frac_of_no_fma_ceiling": round(achieved / PEAK_FP32_NOFMA_TFLOPS, 4),
+            "sample": "8 spp of the full frame, %d segments" % seg}
+
+
+def hbm_traffic_from_profile(workload):
+    """HBM bytes per launch of render_tiles from the committed rocprofv3 --pmc pass
+    (profiles/hbm_traffic.json, written by tools/collect_traffic.py); None if absent."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload, {}).get("bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +116,7 @@ def main():
     ap.add_argument("--workload", default="c4")
     ap.add_argument("--spp-per-step", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-flat-probe", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -158,6 +198,10 @@ def main():
     else:
         seg_total = seg; kern_ms_max = float(np.mean(kernel_ms))
 
+    flat = None
+    if rank == 0 and world == 1 and not args.no_flat_probe and (wl["flat"].counts["n_spheres"] >= 64):
+        flat = flat_scan_probe(r, wl, flops_seg)
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         paths = w * h * sps * args.steps
@@ -184,19 +228,23 @@ def main():
                 "partition": "interleaved 8-row bands, rank r renders bands r, r+N, ...; "
                              "RCCL all_gather of packed pixels per step" if world > 1 else "single GPU",
                 "sampling": "deterministic schedule (RT_SAMPLING_DET), seed 0",
+                "scan": "bounding-sphere tree over the sphere run (results identical to the list-order scan)",
             },
             "roofline": {
                 "bound": "valu", "achieved": round(float(achieved), 3), "peak": PEAK_FP32_VECTOR_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(float(achieved) / PEAK_FP32_VECTOR_TFLOPS, 4),
-                "traffic": None,
-                "kernel": "render_tiles", "kernel_ms": round(float(np.mean(kernel_ms)), 3),
+                "traffic": hbm_traffic_from_profile(args.workload),
+                "kernel": "render_tiles<2>", "kernel_ms": round(float(np.mean(kernel_ms)), 3),
                 "flops_per_segment": flops_seg,
-                "frac_of_no_fma_ceiling": round(float(achieved) / PEAK_FP32_NOFMA_TFLOPS, 4),
-                "note": "algorithmic flops (mul/add counted singly, no FMA in the reference) of the "
-                        "segments one launch traces / mean launch time from HIP events; peak = FP32 "
-                        "vector peak with FMA counted as 2",
+                "note": "achieved = algorithmic flops of the reference's linear scan (18/sphere + 14/plane + "
+                        "18/cube + 45/triangle + 80 per segment, mul/add counted singly) x segments of one launch "
+                        "/ mean launch time (HIP events). The tree skips most of that work, so this exceeds the "
+                        "hardware peak; flat_scan below is the same kernel family doing the full linear scan, "
+                        "where algorithmic = executed work.",
             },
         }
+        if flat is not None:
+            out["roofline"]["flat_scan"] = flat
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, tables)
         print(json.dumps(out), flush=True)
