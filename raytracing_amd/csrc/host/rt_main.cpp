@@ -1,0 +1,157 @@
+// rt_main - headless stand-in for the reference's main() (src/raytracer.rs:96-208)
+// on top of librt_hip.so: builds the scene and camera, renders
+// NUM_FRAMES_TO_RENDER frames with the camera dolly between them
+// (Scene::move_cam, src/scene/mod.rs:78-83), and writes each frame as a binary
+// PPM (src/image/mod.rs:61-67) instead of blitting it to a window.  The worker
+// threads, the channel and the receive loop of the reference are what the
+// library call replaces.
+//
+//   rt_main [--width 600] [--spp 1] [--frames 10] [--aperture 0] [--bounces 10]
+//           [--no-gamma] [--seed 0] [--device 0] [--data DIR] [--out PREFIX]
+//           [--obj FILE [--obj-scale S] [--obj-at X Y Z]] [--chunk N] [--quiet]
+//
+// PREFIX_0000.ppm ... are written when --out is given.  --chunk N renders the
+// samples of a frame N at a time (progressive); the picture is the same.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "scene.hpp"
+
+namespace {
+
+struct Options {
+    uint32_t width = 600, spp = 1, frames = 10, bounces = 10, seed = 0, chunk = 0;
+    int device = 0;
+    float aperture = 0.f, obj_scale = 1.f;
+    rt::vec3 obj_at{0.f, 0.f, 0.f};
+    bool gamma = true, quiet = false;
+    std::string data = "raytracing_amd/data", out, obj;
+};
+
+[[noreturn]] void usage(const char* why) {
+    std::fprintf(stderr, "rt_main: %s\n", why);
+    std::fprintf(stderr,
+                 "usage: rt_main [--width W] [--spp N] [--frames F] [--aperture A] [--bounces B] [--no-gamma]\n"
+                 "               [--seed S] [--device D] [--data DIR] [--out PREFIX] [--chunk N] [--quiet]\n"
+                 "               [--obj FILE [--obj-scale S] [--obj-at X Y Z]]\n");
+    std::exit(2);
+}
+
+Options parse(int argc, char** argv) {
+    Options o;
+    auto need = [&](int& i, int n) {
+        if (i + n >= argc) usage((std::string("missing value after ") + argv[i]).c_str());
+    };
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "--width") { need(i, 1); o.width = (uint32_t)std::strtoul(argv[++i], nullptr, 10); }
+        else if (a == "--spp") { need(i, 1); o.spp = (uint32_t)std::strtoul(argv[++i], nullptr, 10); }
+        else if (a == "--frames") { need(i, 1); o.frames = (uint32_t)std::strtoul(argv[++i], nullptr, 10); }
+        else if (a == "--bounces") { need(i, 1); o.bounces = (uint32_t)std::strtoul(argv[++i], nullptr, 10); }
+        else if (a == "--seed") { need(i, 1); o.seed = (uint32_t)std::strtoul(argv[++i], nullptr, 10); }
+        else if (a == "--chunk") { need(i, 1); o.chunk = (uint32_t)std::strtoul(argv[++i], nullptr, 10); }
+        else if (a == "--device") { need(i, 1); o.device = std::atoi(argv[++i]); }
+        else if (a == "--aperture") { need(i, 1); o.aperture = std::strtof(argv[++i], nullptr); }
+        else if (a == "--no-gamma") o.gamma = false;
+        else if (a == "--quiet") o.quiet = true;
+        else if (a == "--data") { need(i, 1); o.data = argv[++i]; }
+        else if (a == "--out") { need(i, 1); o.out = argv[++i]; }
+        else if (a == "--obj") { need(i, 1); o.obj = argv[++i]; }
+        else if (a == "--obj-scale") { need(i, 1); o.obj_scale = std::strtof(argv[++i], nullptr); }
+        else if (a == "--obj-at") {
+            need(i, 3);
+            o.obj_at.x = std::strtof(argv[++i], nullptr);
+            o.obj_at.y = std::strtof(argv[++i], nullptr);
+            o.obj_at.z = std::strtof(argv[++i], nullptr);
+        } else usage(("unknown option " + a).c_str());
+    }
+    if (o.width < 2 || o.spp == 0) usage("--width must be >= 2 and --spp >= 1");
+    return o;
+}
+
+void check(rt_ctx* ctx, int rc, const char* what) {
+    if (rc == RT_OK) return;
+    std::fprintf(stderr, "rt_main: %s failed (%d): %s\n", what, rc, rt_last_error(ctx));
+    std::exit(1);
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    const Options o = parse(argc, argv);
+    try {
+        // IMAGE (src/raytracer.rs:118-120)
+        const float aspect_ratio = 16.0f / 9.0f;
+        const uint32_t image_width = o.width;
+        const uint32_t image_height = rt_image_height(image_width, aspect_ratio);
+        if (image_height < 2) usage("image too small");
+        std::vector<uint32_t> img_buffer((size_t)image_width * image_height);
+
+        const std::vector<float> disc = rt::load_table(o.data + "/disc_blue_noise_64.txt", 128);
+        const std::vector<float> sphere = rt::load_table(o.data + "/spherical_blue_noise_256.txt", 768);
+        const std::vector<float> screen = rt::load_table(o.data + "/screenspace_blue_noise_128x128.txt", 16384);
+
+        rt::Scene world;
+        rt::HittableList scene = rt::Scene::get_scene();
+        if (!o.obj.empty()) {
+            size_t n = rt::load_obj(o.obj, scene, rt::Lambertian({0.2f, 0.25f, 0.6f}), o.obj_scale, o.obj_at);
+            if (!o.quiet) std::printf("INFO: %zu triangles from %s\n", n, o.obj.c_str());
+        }
+
+        rt_ctx* ctx = nullptr;
+        check(nullptr, rt_create(o.device, &ctx), "rt_create");
+        check(ctx, rt_upload_tables(ctx, disc.data(), sphere.data(), screen.data()), "rt_upload_tables");
+        const rt_scene flat = scene.flatten();
+        check(ctx, rt_upload_scene(ctx, &flat), "rt_upload_scene");
+
+        uint64_t total_segments = 0;
+        double total_ms = 0.0;
+        for (uint32_t frame = 0; frame < o.frames; ++frame) {
+            const rt::Camera cam = world.get_camera(o.aperture, o.spp);
+            check(ctx, rt_set_camera(ctx, &cam.c), "rt_set_camera");
+            const auto start_time = std::chrono::steady_clock::now();
+            check(ctx, rt_begin_frame(ctx, image_width, image_height), "rt_begin_frame");
+            rt_params p;
+            std::memset(&p, 0, sizeof p);
+            p.width = image_width; p.height = image_height;
+            p.spp = cam.samples_per_px;
+            p.max_bounces = o.bounces; p.gamma = o.gamma ? 1u : 0u; p.t_min = 0.001f;
+            p.band_begin = 0; p.band_stride = 1;
+            p.sampling_mode = RT_SAMPLING_DET; p.seed = o.seed;
+            const uint32_t chunk = o.chunk ? o.chunk : p.spp;
+            for (uint32_t s = 0; s < p.spp; s += chunk) {
+                p.sample_begin = s;
+                p.sample_count = (p.spp - s < chunk) ? p.spp - s : chunk;
+                check(ctx, rt_render(ctx, &p), "rt_render");
+            }
+            check(ctx, rt_read_packed(ctx, img_buffer.data(), img_buffer.size()), "rt_read_packed");
+            const double ms =
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - start_time).count();
+            uint64_t segments = 0;
+            check(ctx, rt_ray_count(ctx, &segments), "rt_ray_count");
+            total_segments += segments;
+            total_ms += ms;
+            if (!o.out.empty()) {
+                char name[32];
+                std::snprintf(name, sizeof name, "_%04u.ppm", frame);
+                const std::string path = o.out + name;
+                check(ctx, rt_write_ppm(path.c_str(), img_buffer.data(), image_width, image_height), "rt_write_ppm");
+            }
+            if (!o.quiet)
+                std::printf("frame %u: COUNTER %u, %.3f ms, FPS: %.2f, %.1f Mrays/s\n", frame, world.counter, ms,
+                            1000.0 / ms, (double)segments / ms * 1e-3);
+            world.move_cam();
+        }
+        std::printf("{\"frames\": %u, \"width\": %u, \"height\": %u, \"spp\": %u, \"segments\": %llu, \"ms\": %.3f}\n",
+                    o.frames, image_width, image_height, o.spp, (unsigned long long)total_segments, total_ms);
+        rt_destroy(ctx);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "rt_main: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

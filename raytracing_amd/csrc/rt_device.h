@@ -35,8 +35,9 @@ struct DevRun {
     uint32_t order_base;  // DevScene::order + order_base: list position in run -> slot offset
     uint32_t level_base[DEV_MAX_LEVELS];   // first step of each level
     float level_keep[DEV_MAX_LEVELS];      // 1 - eps of each level
-    float reach;          // RUN_TREE: max over balls of |centre| + radius
-    uint32_t pad[7];
+    float reach;          // RUN_TREE: max over bounded balls of |centre| + radius
+    float inv_2rho;       // RUN_TREE of spheres: 1 / (2 * smallest |radius|), +inf when that is 0
+    uint32_t pad[6];
 };
 
 // The primitive list in device memory.  All arrays are read with wave-uniform

@@ -133,7 +133,16 @@ __device__ __forceinline__ RunView load_run(const SceneView &sc, uint32_t r) {
 __host__ __device__ constexpr int waves_of(int modes) { return (modes & 2) ? RTK_TREE_WAVES : 4; }
 constexpr int TILE = 8;   // 8x8 pixels per wavefront
 
-struct TreeTable { uint32_t base[DEV_MAX_LEVELS]; float keep[DEV_MAX_LEVELS]; };
+struct TreeTable {
+    uint32_t base[DEV_MAX_LEVELS];
+    float keep[DEV_MAX_LEVELS];
+    // closest-hit state of every lane when it entered the run being walked, for the lanes
+    // that have to start the run over in list order
+    float entry_t[64];
+    int32_t entry_id[64];
+    uint32_t entry_slot[64];
+    uint32_t entry_bits[64];   // kind + 1 | ff << 8 | ff_shared << 9
+};
 
 // MODES: bit 0 = the scene has RUN_FLAT runs, bit 1 = it has RUN_TREE runs; the
 // kernel is compiled once per combination so that scenes without a tree do not
@@ -402,38 +411,28 @@ __device__ __forceinline__ void scan_flat(const SceneView &sc, const RunView &ru
 // A child ball is skipped when the RAY (not the line) cannot touch it:
 //   |o|^2 keep - 2 o.c - max((c-o).u, 0)^2 > thr          (misses sideways / lies behind)
 //   (c-o).u - R > closest_so_far * |d| (+ rounding slack)  (lies beyond the best hit)
-// Rays whose numbers could make a hit distance NaN (zero or non-finite
-// direction, NaN closest_so_far inherited from an earlier run) are kept out
-// of the walk and take the run in list order instead, because with NaN the
-// reference's result depends on the visiting order (src/geometry/mod.rs:74:
-// both comparisons fail and the sphere is accepted).
+// A lane leaves the walk as soon as its closest_so_far turns NaN (see scan_tree).
 // ----------------------------------------------------------------------
 template <int KIND>
-__device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &run, const Cull &cull, bool tracing,
+__device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &run, const Cull &cull, bool walking,
                                           TreeTable &tbl, const f4 *tree_top, uint32_t lds_from_level,
                                           const Ray &ray, float a, float t_min, Hit &h, bool &ff_shared) {
-    const float big = 1e18f;
-    const bool tame = a > 0.0f && a < big && h.t == h.t &&
-                      __builtin_fabsf(ray.o.x) < big && __builtin_fabsf(ray.o.y) < big && __builtin_fabsf(ray.o.z) < big;
-    const bool wild = tracing && !tame;
-    if (__builtin_amdgcn_ballot_w64(wild) != 0ull) {
-        for (uint32_t k = 0; k < run.count; ++k) {
-            const uint32_t slot = run.first + sc.order[run.order_base + k];
-            if (wild) {
-                if (KIND == DEV_SPHERE) sphere_exact(sc, slot, (int32_t)(run.id0 + k), ray, a, t_min, h, ff_shared);
-                else tri_exact(sc, slot, (int32_t)(run.id0 + k), ray, t_min, h, ff_shared);
-            }
-        }
-    }
-    const bool walking = tracing && tame;
-    if (__builtin_amdgcn_ballot_w64(walking) == 0ull) return;
-
     // per-level constants where a lane can index them by its own level
 #pragma unroll
     for (uint32_t L = 0; L < DEV_MAX_LEVELS; ++L) { tbl.base[L] = run.lo[8 + L]; tbl.keep[L] = __uint_as_float(run.hi[L]); }
     const float len = __builtin_sqrtf(a);
-    // slack of the "beyond the best hit" test: (c-o).u is off by < 10 ulp (|o|+|c|)
-    const float far_pad = (__builtin_sqrtf(cull.oo) + __uint_as_float(run.hi[8])) * (1.0f / 1048576.0f);
+    // Slack of the "beyond the best hit" test.  (c-o).u and the reference's root are off by
+    // < 10 ulp (|o|+|c|): 2^-20 S with S = |o| + reach >= |o-c| for every ball of the run.
+    // For spheres the f32 discriminant of Sphere::hit is uncertain by kappa a |o-c|^2 with
+    // kappa < 2^-19, so the root it yields lies on a sphere of radius sqrt(r^2 + kappa |o-c|^2)
+    // around the centre rather than r: up to min(sqrt(kappa) S, kappa S^2 / (2 r_min)) further
+    // out than any bounding ball accounts for.
+    const float S = __builtin_sqrtf(cull.oo) + __uint_as_float(run.hi[8]);
+    float far_pad = S * (1.0f / 1048576.0f);
+    if (KIND == DEV_SPHERE) {
+        const float kS = S * (1.0f / 524288.0f);
+        far_pad += __builtin_fminf(S * 1.3811e-3f, kS * S * __uint_as_float(run.hi[9]));
+    }
     const float far_len = len * (1.0f + 1.0f / 1048576.0f);
     const uint32_t top = run.n_levels - 1u;
     const RT_CONST_AS f4 *nodes = sc.tree_rec;
@@ -515,7 +514,7 @@ __device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &ru
                 } else {
                     // next pending sibling, of this node or of its nearest ancestor that has one
                     const unsigned long long rest = pend >> (8u * L);
-                    if (rest == 0ull) {
+                    if (rest == 0ull || h.t != h.t) {
                         act = false;
                     } else {
                         const uint32_t z = (uint32_t)__builtin_ctzll(rest);
@@ -525,6 +524,53 @@ __device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &ru
                         pend &= ~(1ull << (8u * L + k));
                     }
                 }
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------
+// One RUN_TREE run for the lanes of a wave.
+// The reference's result depends on the visiting order only while a hit
+// distance is NaN (src/geometry/mod.rs:74: both comparisons fail and the
+// sphere is accepted, whatever is held).  Rays that enter with such numbers
+// (zero or non-finite direction, NaN closest_so_far inherited from an earlier
+// run, huge origins) are kept out of the walk; a lane whose closest_so_far
+// turns NaN during the walk (a primitive with NaN/overflowing coordinates, a
+// triangle whose determinant underflows) drops out of it.  Both kinds then
+// take the run in list order, the second from the state it entered with.
+// ----------------------------------------------------------------------
+template <int KIND>
+__device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &run, const Cull &cull, bool tracing,
+                                          TreeTable &tbl, const f4 *tree_top, uint32_t lds_from_level,
+                                          const Ray &ray, float a, float t_min, Hit &h, bool &ff_shared) {
+    const float big = 1e18f;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool tame = a > 1e-30f && a < big && h.t == h.t &&
+                      __builtin_fabsf(ray.o.x) < big && __builtin_fabsf(ray.o.y) < big && __builtin_fabsf(ray.o.z) < big;
+    const bool walking = tracing && tame;
+    bool listed = tracing && !tame;   // lanes that take the run in list order
+    if (__builtin_amdgcn_ballot_w64(walking) != 0ull) {
+        if (walking) {
+            tbl.entry_t[lane] = h.t;
+            tbl.entry_id[lane] = h.id;
+            tbl.entry_slot[lane] = h.slot;
+            tbl.entry_bits[lane] = (uint32_t)(h.kind + 1) | ((uint32_t)h.ff << 8) | ((uint32_t)ff_shared << 9);
+        }
+        walk_tree<KIND>(sc, run, cull, walking, tbl, tree_top, lds_from_level, ray, a, t_min, h, ff_shared);
+        if (walking && h.t != h.t) {
+            const uint32_t bits = tbl.entry_bits[lane];
+            h.t = tbl.entry_t[lane]; h.id = tbl.entry_id[lane]; h.slot = tbl.entry_slot[lane];
+            h.kind = (int)(bits & 0xffu) - 1; h.ff = (bits >> 8) & 1u; ff_shared = (bits >> 9) & 1u;
+            listed = true;
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(listed) != 0ull) {
+        for (uint32_t k = 0; k < run.count; ++k) {
+            const uint32_t slot = run.first + sc.order[run.order_base + k];
+            if (listed) {
+                if (KIND == DEV_SPHERE) sphere_exact(sc, slot, (int32_t)(run.id0 + k), ray, a, t_min, h, ff_shared);
+                else tri_exact(sc, slot, (int32_t)(run.id0 + k), ray, t_min, h, ff_shared);
             }
         }
     }

@@ -33,6 +33,19 @@ float round_up(double v) {
     return f;
 }
 
+// A ball the kernel's rejection tests cannot speak for: NaN or infinite numbers, or
+// magnitudes at which the tests' intermediates could overflow.  It is stored as centre
+// 0 with an infinite radius (never rejected, nothing non-finite enters the kernel's
+// arithmetic), and so is every ball above it in the tree.
+const double BALL_RANGE = 1e15;
+const Ball UNBOUNDED = {0.0, 0.0, 0.0, INFINITY};
+bool unbounded(const Ball &b) { return !(std::abs(b.r) < BALL_RANGE); }
+Ball bounded_or_unbounded(const Ball &b) {
+    if (std::abs(b.x) < BALL_RANGE && std::abs(b.y) < BALL_RANGE && std::abs(b.z) < BALL_RANGE && std::abs(b.r) < BALL_RANGE)
+        return b;   // comparisons with NaN are false
+    return UNBOUNDED;
+}
+
 // Rejection record {cx,cy,cz,thr} of the ball (c, r) at margin eps:
 //   thr = r^2 (1+eps) - |c|^2 (1-eps), rounded up; the kernel rejects when
 //   |o|^2 (1-eps) - 2 o.c - ((c-o).u)^2 > thr.
@@ -42,7 +55,7 @@ float4 reject_record(const Ball &b, double eps) {
     const double c2 = b.x * b.x + b.y * b.y + b.z * b.z;
     const double r2 = b.r * b.r;
     float thr = INFINITY;
-    if (c2 < 1e30 && r2 < 1e30 && c2 + r2 > 1e-24 && eps <= 1.0 / 16.0)
+    if (!unbounded(b) && c2 + r2 > 1e-24 && eps <= 1.0 / 16.0)
         thr = round_up(r2 * (1.0 + eps) - c2 * (1.0 - eps));
     return make_float4((float)b.x, (float)b.y, (float)b.z, thr);
 }
@@ -77,7 +90,7 @@ struct Arranger {
         const size_t gl = groups / 2, left = gl * cap;
         std::nth_element(idx.begin() + a, idx.begin() + a + left, idx.begin() + a + n, [&](uint32_t p, uint32_t q) {
             const double u = coord(p, axis), v = coord(q, axis);
-            return u < v || (u == v && p < q);   // total order: NaN-free input assumed, ties by index
+            return u < v || (u == v && p < q);   // total order: centres are finite, ties by index
         });
         split(a, left, gl, cap);
         split(a + left, n - left, groups - gl, cap);
@@ -95,8 +108,6 @@ struct Arranger {
 std::vector<uint32_t> tree_order(const std::vector<Ball> &balls) {
     std::vector<uint32_t> order(balls.size());
     std::iota(order.begin(), order.end(), 0u);
-    for (const Ball &b : balls)
-        if (!(b.x == b.x && b.y == b.y && b.z == b.z)) return order;   // NaN centres: leave the list order
     size_t steps = (balls.size() + 7) / 8, cap = 8;
     while (steps > 8) { steps = (steps + 7) / 8; cap *= 8; }   // cap = primitives under one child of the top node
     Arranger ar{balls, order};
@@ -141,7 +152,12 @@ void build_tree(HostScene &sc, DevRun &run, const std::vector<Ball> &leaves, dou
                 bool scale_with_ratio) {
     struct Node { Ball b; double rho_min; };
     std::vector<Node> cur(leaves.size());
-    for (size_t k = 0; k < leaves.size(); ++k) cur[k] = {leaves[k], std::abs(leaves[k].r)};
+    double rho_all = INFINITY;
+    for (size_t k = 0; k < leaves.size(); ++k) {
+        cur[k] = {leaves[k], std::abs(leaves[k].r)};
+        if (!unbounded(leaves[k])) rho_all = std::min(rho_all, std::abs(leaves[k].r));
+    }
+    run.inv_2rho = rho_all > 0 && rho_all < INFINITY ? round_up(0.5 / rho_all) : INFINITY;
     uint32_t level = 0;
     double eps = leaf_eps;
     for (;;) {
@@ -155,7 +171,7 @@ void build_tree(HostScene &sc, DevRun &run, const std::vector<Ball> &leaves, dou
             recs.push_back(rec);
             radii.push_back(round_up(std::abs(n.b.r) * (1.0 + 1e-6)));
             const double reach = std::sqrt(n.b.x * n.b.x + n.b.y * n.b.y + n.b.z * n.b.z) + std::abs(n.b.r);
-            if (reach < 1e30) run.reach = std::max(run.reach, round_up(reach));
+            if (!unbounded(n.b)) run.reach = std::max(run.reach, round_up(reach));
         }
         while (recs.size() % 8) { recs.push_back(NEVER_PASS); radii.push_back(0.0f); }
         run.level_base[level] = (uint32_t)(sc.tree_rec.size() / 10);   // in steps (10 float4 each)
@@ -174,13 +190,16 @@ void build_tree(HostScene &sc, DevRun &run, const std::vector<Ball> &leaves, dou
             const size_t b0 = s * 8, b1 = std::min(cur.size(), b0 + 8);
             double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
             double rho_min = INFINITY;
+            bool open = false;
             for (size_t k = b0; k < b1; ++k) {
                 const Ball &c = cur[k].b;
+                if (unbounded(c)) { open = true; continue; }
                 const double p[3] = {c.x, c.y, c.z};
                 const double r = std::abs(c.r);
                 for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[a] - r); hi[a] = std::max(hi[a], p[a] + r); }
                 rho_min = std::min(rho_min, cur[k].rho_min);
             }
+            if (open) { up[s] = {UNBOUNDED, rho_min}; continue; }
             Ball m{(lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, (lo[2] + hi[2]) / 2, 0.0};
             // the float centre the kernel sees is what distances are measured from
             m.x = (float)m.x; m.y = (float)m.y; m.z = (float)m.z;
@@ -190,17 +209,21 @@ void build_tree(HostScene &sc, DevRun &run, const std::vector<Ball> &leaves, dou
                 m.r = std::max(m.r, d + std::abs(c.r));
             }
             m.r *= 1.0 + 1e-6;
-            if (!(m.r == m.r)) m.r = INFINITY;   // NaN input: never rejected
+            m = bounded_or_unbounded(m);
             up[s] = {m, rho_min};
-            if (rho_min > 0 && m.r < INFINITY) max_ratio = std::max(max_ratio, m.r / rho_min);
-            else max_ratio = INFINITY;
+            if (unbounded(m)) continue;
+            max_ratio = std::max(max_ratio, rho_min > 0 ? m.r / rho_min : INFINITY);
         }
         if (scale_with_ratio) {
+            // 2^-7 is enough whatever the ratio: a ray that clears a ball (C, R) by
+            // D^2 - R^2 > eps S (S = |o|^2 + |C|^2 + R^2) passes every point of it at
+            // D - R > eps S / (D + R) >= eps sqrt(S/3), and a sphere of any radius inside
+            // the ball is missed by Sphere::hit once the gap exceeds sqrt(kappa) |o-c| <=
+            // sqrt(3 kappa S), kappa = 19.5 ulp: eps >= 3 sqrt(kappa) = 3.3e-3 suffices.
             int j = 1;
             while (std::ldexp(1.0, j) < 2.0 * max_ratio && j < 40) ++j;
-            eps = leaf_eps * std::ldexp(1.0, j);
+            eps = std::min(leaf_eps * std::ldexp(1.0, j), 1.0 / 128.0);
         }
-        // a level whose margin would exceed 1/16 rejects nothing (reject_record caps it)
         cur.swap(up);
         ++level;
     }
@@ -266,7 +289,7 @@ int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::strin
             std::vector<Ball> balls(count);
             for (uint32_t k = 0; k < count; ++k) {
                 const uint32_t src = list[id + k].k;
-                balls[k] = {s->sph_cx[src], s->sph_cy[src], s->sph_cz[src], s->sph_r[src]};
+                balls[k] = bounded_or_unbounded({s->sph_cx[src], s->sph_cy[src], s->sph_cz[src], s->sph_r[src]});
             }
             if (count >= DEV_TREE_MIN_RUN && use_tree) {
                 run.mode = RUN_TREE;
@@ -338,8 +361,7 @@ int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::strin
                     b.r = std::max(b.r, std::sqrt((v[i][0] - b.x) * (v[i][0] - b.x) + (v[i][1] - b.y) * (v[i][1] - b.y) +
                                                   (v[i][2] - b.z) * (v[i][2] - b.z)));
                 b.r *= 1.0 + 1e-3;
-                if (!(b.r == b.r)) b.r = INFINITY;
-                balls[k] = b;
+                balls[k] = bounded_or_unbounded(b);
             }
             if (count >= DEV_TREE_MIN_RUN && use_tree) {
                 run.mode = RUN_TREE;

@@ -1,0 +1,174 @@
+""".obj reader, the C++ host mirror and the headless driver.
+
+CPU part: the reader's format rules, and that the C++ mirror
+(csrc/host/scene.hpp) produces field for field what the Python mirror does.
+GPU part: the driver binary (a stand-in for the reference's main,
+src/raytracer.rs:96-208) writes the frames the oracle computes for the same
+dolly positions, bit for bit."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from raytracing_amd import (HittableList, Lambertian, Metal, Scene, Triangle, image_height, load_obj, make_params,
+                            parse_obj, write_obj)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "raytracing_amd")
+
+OBJ_TEXT = """# a quad, a triangle with negative indices, and records to skip
+o thing
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+vn 0 0 1
+vt 0.5 0.5
+f 1/1/1 2/1/1 3/1/1 4/1/1
+v 0.5 0.5 1e0
+f -1 -5 -4
+s off
+usemtl none
+f 1//1 3//1 5//1
+"""
+
+
+def test_parse_obj_rules():
+    verts, tris = parse_obj(OBJ_TEXT)
+    assert len(verts) == 5 and verts[4] == (0.5, 0.5, 1.0)
+    # quad -> fan (0,1,2),(0,2,3); negative indices count back from the vertices read so far
+    assert tris == [(0, 1, 2), (0, 2, 3), (4, 0, 1), (0, 2, 4)]
+
+
+@pytest.mark.parametrize("bad", ["v 1 2\n", "v 0 0 0\nf 1 2 3\n", "v 0 0 0\nf 0 1 1\n", "v 0 0 0\nf 1 1\n",
+                                 "v 0 0 0\nf -2 1 1\n", "v a b c\n"])
+def test_parse_obj_rejects(bad):
+    with pytest.raises(ValueError):
+        parse_obj(bad)
+
+
+def test_load_obj_appends_in_file_order(tmp_path):
+    path = tmp_path / "m.obj"
+    path.write_text(OBJ_TEXT)
+    scene = Scene.get_scene()
+    n = load_obj(str(path), scene, Lambertian((0.1, 0.2, 0.3)), scale=2.0, translate=(1.0, 0.0, -1.0))
+    assert n == 4 and len(scene) == 12
+    t = scene.list[10]
+    assert isinstance(t, Triangle) and t.v0 == (2.0, 1.0, 1.0) and t.v1 == (1.0, 0.0, -1.0)
+    flat = scene.flatten()
+    assert list(flat.arrays["tri_id"]) == [8, 9, 10, 11]
+
+
+def test_write_obj_round_trip(tmp_path):
+    rng = np.random.default_rng(3)
+    verts = rng.standard_normal((20, 3)).astype(np.float32)
+    tris = [tuple(int(x) for x in rng.choice(20, 3, replace=False)) for _ in range(30)]
+    path = tmp_path / "r.obj"
+    write_obj(str(path), verts, tris)
+    v2, t2 = parse_obj(path.read_text())
+    assert t2 == tris
+    assert np.array_equal(np.array(v2, dtype=np.float32), verts)
+
+
+def _dump_scene(tmp_path, args=()):
+    exe = tmp_path / "dump_scene"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(PKG, "csrc", "host"), os.path.join(ROOT, "tests", "cpp", "dump_scene.cpp"),
+                           "-o", str(exe), "-L" + PKG, "-lrt_hip", "-Wl,-rpath," + PKG])
+    out = subprocess.check_output([str(exe)] + [str(a) for a in args], text=True)
+    fields = {}
+    for line in out.splitlines():
+        parts = line.split()
+        if parts[0] == "counter":
+            fields[("counter", int(parts[1]))] = parts[2:]
+        else:
+            fields[parts[0]] = parts[1:]
+    return fields
+
+
+def test_cpp_mirror_equals_python_mirror(tmp_path):
+    path = tmp_path / "m.obj"
+    path.write_text(OBJ_TEXT)
+    dump = _dump_scene(tmp_path, [path, 0.37, 1.3, 0.3, 0.6])
+    scene = Scene.get_scene()
+    load_obj(str(path), scene, Metal((0.5, 0.25, 0.125), 0.3), scale=0.37, translate=(1.3, 0.3, 0.6))
+    flat = scene.flatten()
+    for name, arr in flat.arrays.items():
+        if arr.dtype == np.float32:
+            expect = ["%08x" % b for b in arr.view(np.uint32)]
+        else:
+            expect = [str(int(v)) for v in arr.view(np.uint32)]
+        assert dump[name] == expect, name
+    # dolly camera: COUNTER 0, 1, 99, and 100 steps wraps to 0 (src/scene/mod.rs:78-83)
+    assert sorted(k[1] for k in dump if isinstance(k, tuple)) == [0, 1, 99]   # the 100th step is 0 again
+    for counter in (0, 1, 99):
+        Scene.COUNTER = counter
+        cam = Scene.get_camera(aperture=0.1, samples_per_px=4)
+        Scene.COUNTER = 0
+        bits = ["%08x" % b for b in np.frombuffer(bytes(cam.struct), dtype=np.uint32)[:19]]
+        assert dump[("counter", counter)] == bits
+
+
+def test_driver_fails_loudly_without_gpu_or_with_bad_arguments():
+    exe = os.path.join(PKG, "rt_main")
+    assert os.path.exists(exe), "build the driver first: make -C raytracing_amd/csrc"
+    r = subprocess.run([exe, "--bogus"], capture_output=True, text=True)
+    assert r.returncode == 2 and "unknown option" in r.stderr
+    r = subprocess.run([exe, "--data", "/nonexistent", "--frames", "1"], capture_output=True, text=True)
+    assert r.returncode == 1 and "cannot open" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, "--frames", "1", "--data", os.path.join(PKG, "data")], capture_output=True, text=True)
+        assert r.returncode == 1 and "rt_create failed" in r.stderr
+
+
+def _read_ppm(path):
+    raw = open(path, "rb").read()
+    head, rest = raw.split(b"\n", 1)
+    magic, w, h, mx = head.split()
+    assert magic == b"P6" and mx == b"255"
+    rgb = np.frombuffer(rest, dtype=np.uint8).reshape(int(h), int(w), 3).astype(np.uint32)
+    return (rgb[..., 0] << 16) | (rgb[..., 1] << 8) | rgb[..., 2]
+
+
+@pytest.mark.gpu
+def test_driver_frames_equal_oracle(tmp_path, oracle, tables):
+    """three frames of the dolly, progressive chunks, depth of field"""
+    exe = os.path.join(PKG, "rt_main")
+    w, spp = 160, 3
+    h = image_height(w)
+    out = subprocess.check_output([exe, "--width", str(w), "--spp", str(spp), "--frames", "3", "--aperture", "0.1",
+                                   "--chunk", "2", "--data", os.path.join(PKG, "data"), "--out",
+                                   str(tmp_path / "f")], text=True, timeout=100)
+    assert '"frames": 3' in out
+    flat = Scene.get_scene().flatten()
+    total = 0
+    for frame in range(3):
+        cam = oracle.scene_camera(frame, 0.1)
+        acc, _, seg = oracle.render(flat, cam, tables, make_params(w, h, spp=spp))
+        total += seg
+        assert np.array_equal(_read_ppm(str(tmp_path / ("f_%04d.ppm" % frame))), oracle.pack(acc)), frame
+    assert '"segments": %d' % total in out
+
+
+@pytest.mark.gpu
+def test_driver_with_obj_mesh_equals_oracle(tmp_path, oracle, tables):
+    from raytracing_amd import workloads
+    triples = workloads.uv_sphere_mesh(center=(0.0, 0.0, 0.0), radius=1.0, n_lat=12, n_lon=16)
+    verts = [np.float32(v) for t in triples for v in t]
+    tris = [(3 * k, 3 * k + 1, 3 * k + 2) for k in range(len(triples))]
+    path = tmp_path / "ball.obj"
+    write_obj(str(path), verts, tris)
+    exe = os.path.join(PKG, "rt_main")
+    w, spp = 128, 2
+    h = image_height(w)
+    subprocess.check_output([exe, "--width", str(w), "--spp", str(spp), "--frames", "1", "--obj", str(path),
+                             "--obj-scale", "0.4", "--obj-at", "1.3", "0.4", "0.6", "--data",
+                             os.path.join(PKG, "data"), "--out", str(tmp_path / "m"), "--quiet"], text=True, timeout=100)
+    scene = Scene.get_scene()
+    n = load_obj(str(path), scene, Lambertian((0.2, 0.25, 0.6)), scale=0.4, translate=(1.3, 0.4, 0.6))
+    assert n == len(tris)
+    acc, _, _ = oracle.render(scene.flatten(), oracle.scene_camera(0, 0.0), tables, make_params(w, h, spp=spp))
+    assert np.array_equal(_read_ppm(str(tmp_path / "m_0000.ppm")), oracle.pack(acc))
