@@ -89,8 +89,13 @@ typedef struct rt_scene {
      * advertises .obj meshes, the code has none).  Semantics defined here:
      * two-sided Moller-Trumbore with e1 = v1-v0, e2 = v2-v0, plain f32
      * mul/add, miss when det == 0, u < 0, u > 1, v < 0, u+v > 1,
-     * t < t_min or t_max < t; outward normal unit(cross(e1, e2)), then
-     * set_face_normal and the material scatter like a Sphere. */
+     * t < t_min or t_max < t.  A hit then counts only if the hit point
+     * p = o + t*d lies in the triangle's bounding ball, |p - g|^2 <= R2 with
+     * g = v0 + (e1 + e2) * (1/3) and R2 = 1.0078125 * max |vertex - g|^2 +
+     * 2^-30 |g|^2: evaluated in f32, the barycentric test alone accepts points
+     * far outside a sliver or a triangle seen edge-on, and may yield NaN.
+     * Outward normal unit(cross(e1, e2)), then set_face_normal and the material
+     * scatter like a Sphere. */
     uint32_t n_tris;
     const float *tri_v0x, *tri_v0y, *tri_v0z;
     const float *tri_v1x, *tri_v1y, *tri_v1z;

@@ -239,7 +239,9 @@ __device__ __forceinline__ void sphere_exact(const SceneView &sc, uint32_t slot,
         ff_shared = dot(ray.d, outward) < 0.0f;
     }
 }
-// Triangle (defined by rt_hip.h, absent from the reference)
+// Triangle (defined by rt_hip.h, absent from the reference): Moller-Trumbore, then the
+// bounding-ball gate that keeps the f32 barycentric test from accepting points far outside
+// a sliver or an edge-on triangle
 __device__ __forceinline__ void tri_exact(const SceneView &sc, uint32_t slot, int32_t id, const Ray &ray,
                                           float t_min, Hit &h, bool &ff_shared) {
     const f4 v0 = sc.tris[3 * slot];
@@ -258,6 +260,9 @@ __device__ __forceinline__ void tri_exact(const SceneView &sc, uint32_t slot, in
     if (v < 0.0f || u + v > 1.0f) return;
     float t = f * dot(E2, q);
     if (t < t_min || h.t < t) return;
+    // gate: the hit point must lie in the ball around g = v0 + (e1 + e2)/3 (e1.w = radius^2)
+    V3 w = (ray.o + ray.d * t) - (mk(v0.x, v0.y, v0.z) + (E1 + E2) * 0.33333334f);
+    if (!(len2(w) <= e1.w)) return;
     if (t == h.t && id < h.id) return;
     h.t = t; h.kind = DEV_TRI; h.slot = slot; h.id = id;
     if (sc.need_ff_shared) {

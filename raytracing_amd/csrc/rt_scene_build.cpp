@@ -46,6 +46,27 @@ Ball bounded_or_unbounded(const Ball &b) {
     return UNBOUNDED;
 }
 
+// Gate of the triangle test (rt_hip.h): the ball around g = v0 + (e1 + e2)/3 with squared
+// radius 1.0078125 * max |vertex - g|^2 + 2^-30 |g|^2, every step in binary32, left to
+// right, from the f32 edges the kernel uses.
+struct TriGate { float cx, cy, cz, r2; };
+TriGate tri_gate(const rt_scene *s, uint32_t k) {
+    const float ax = s->tri_v0x[k], ay = s->tri_v0y[k], az = s->tri_v0z[k];
+    const float e1x = s->tri_v1x[k] - ax, e1y = s->tri_v1y[k] - ay, e1z = s->tri_v1z[k] - az;
+    const float e2x = s->tri_v2x[k] - ax, e2y = s->tri_v2y[k] - ay, e2z = s->tri_v2z[k] - az;
+    const float third = 0.33333334f;
+    const float gx = ax + (e1x + e2x) * third, gy = ay + (e1y + e2y) * third, gz = az + (e1z + e2z) * third;
+    auto d2 = [&](float px, float py, float pz) {
+        const float wx = px - gx, wy = py - gy, wz = pz - gz;
+        return wx * wx + wy * wy + wz * wz;
+    };
+    float m = d2(ax, ay, az);
+    const float m1 = d2(ax + e1x, ay + e1y, az + e1z), m2 = d2(ax + e2x, ay + e2y, az + e2z);
+    if (m1 > m) m = m1;
+    if (m2 > m) m = m2;
+    return {gx, gy, gz, m * 1.0078125f + (gx * gx + gy * gy + gz * gz) * 9.313225746154785e-10f};
+}
+
 // Rejection record {cx,cy,cz,thr} of the ball (c, r) at margin eps:
 //   thr = r^2 (1+eps) - |c|^2 (1-eps), rounded up; the kernel rejects when
 //   |o|^2 (1-eps) - 2 o.c - ((c-o).u)^2 > thr.
@@ -144,10 +165,13 @@ void append_tree_step(std::vector<float4> &out, const float4 *recs, const float 
 // the leaf's own margin (a near miss of the ball at a point where a small leaf
 // touches it from inside is the binding case).  That scaling is what spheres
 // need, because the f32 discriminant of Sphere::hit is uncertain by an amount
-// that does not shrink with the sphere (about 20 ulp of |o-c|^2).  The f32
-// triangle test is uncertain by a DISTANCE of a few ulp of |o-v0| whatever the
-// triangle's size, which one constant margin covers at every level
-// (scale_with_ratio = false).
+// that does not shrink with the sphere (about 20 ulp of |o-c|^2); it is capped
+// at 2^-7, which is enough for any ratio.  A triangle hit is gated by its ball
+// (tri_gate), so the only uncertainty is that of the hit point o + t*d, a
+// DISTANCE of a few ulp of |o| + |o-g| whatever the triangle's size: a ray that
+// clears a ball (C, R) with D^2 - R^2 > eps (|o|^2 + |C|^2 + R^2) passes it at
+// more than eps (|o| + |C| + R) / 3, which one constant margin covers at every
+// level (scale_with_ratio = false).
 void build_tree(HostScene &sc, DevRun &run, const std::vector<Ball> &leaves, double leaf_eps,
                 bool scale_with_ratio) {
     struct Node { Ball b; double rho_min; };
@@ -269,7 +293,7 @@ int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::strin
     }
 
     const double LEAF_EPS_SPHERE = 1.0 / 65536.0;   // proven bound of the kernel's test, see cull_pair
-    const double LEAF_EPS_TRI = 1.0 / 4096.0;       // guard band of triangle balls, all levels
+    const double LEAF_EPS_TRI = 1.0 / 65536.0;      // guard band of triangle balls, all levels
 
     for (uint32_t id = 0; id < n;) {
         const int kind = list[id].kind;
@@ -349,19 +373,13 @@ int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::strin
             std::vector<uint32_t> order(count);
             std::iota(order.begin(), order.end(), 0u);
             std::vector<Ball> balls(count);
+            std::vector<float> gate_r2(count);
             for (uint32_t k = 0; k < count; ++k) {
                 const uint32_t src = list[id + k].k;
-                const double v[3][3] = {{s->tri_v0x[src], s->tri_v0y[src], s->tri_v0z[src]},
-                                        {s->tri_v1x[src], s->tri_v1y[src], s->tri_v1z[src]},
-                                        {s->tri_v2x[src], s->tri_v2y[src], s->tri_v2z[src]}};
-                Ball b{(v[0][0] + v[1][0] + v[2][0]) / 3, (v[0][1] + v[1][1] + v[2][1]) / 3,
-                       (v[0][2] + v[1][2] + v[2][2]) / 3, 0.0};
-                b.x = (float)b.x; b.y = (float)b.y; b.z = (float)b.z;
-                for (int i = 0; i < 3; ++i)
-                    b.r = std::max(b.r, std::sqrt((v[i][0] - b.x) * (v[i][0] - b.x) + (v[i][1] - b.y) * (v[i][1] - b.y) +
-                                                  (v[i][2] - b.z) * (v[i][2] - b.z)));
-                b.r *= 1.0 + 1e-3;
-                balls[k] = bounded_or_unbounded(b);
+                const TriGate g = tri_gate(s, src);
+                gate_r2[k] = g.r2;
+                // every point the gate lets through is within sqrt(r2) of the centre
+                balls[k] = bounded_or_unbounded({g.cx, g.cy, g.cz, std::sqrt((double)g.r2) * (1.0 + 1e-6)});
             }
             if (count >= DEV_TREE_MIN_RUN && use_tree) {
                 run.mode = RUN_TREE;
@@ -377,7 +395,7 @@ int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::strin
                 const float e1x = s->tri_v1x[src] - ax, e1y = s->tri_v1y[src] - ay, e1z = s->tri_v1z[src] - az;
                 const float e2x = s->tri_v2x[src] - ax, e2y = s->tri_v2y[src] - ay, e2z = s->tri_v2z[src] - az;
                 sc.tris.push_back(make_float4(ax, ay, az, bits_to_float(s->tri_mat[src])));
-                sc.tris.push_back(make_float4(e1x, e1y, e1z, 0.f));
+                sc.tris.push_back(make_float4(e1x, e1y, e1z, gate_r2[order[k]]));
                 sc.tris.push_back(make_float4(e2x, e2y, e2z, 0.f));
                 sc.tri_id.push_back(id + order[k]);
                 sc.order[run.order_base + order[k]] = k;

@@ -272,3 +272,15 @@ def test_list_order_scan_equals_tree_on_the_gpu(renderer):
         del os.environ["RT_HIP_FLAT_SCAN"]
     assert np.array_equal(_bits(tree[0]), _bits(flat[0]))
     assert np.array_equal(tree[1], flat[1]) and np.array_equal(tree[2], flat[2]) and tree[3] == flat[3]
+
+
+def test_fuzz_tree_against_list_order_scan():
+    """a few hundred random scenes (slivers, lattices of touching spheres, coplanar sheets,
+    extents from 0.1 to 1000, cameras inside and far outside) at 1280x720: the tree scan
+    and the list-order scan of the same library must agree bit for bit"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_tree_vs_list.py"), "20", "100000"],
+                         capture_output=True, text=True, timeout=200)
+    assert out.returncode == 0 and "mismatches 0" in out.stdout.splitlines()[-1], out.stdout[-2000:] + out.stderr[-2000:]

@@ -268,6 +268,73 @@ def test_triangle_definition(oracle, tables):
     assert not oracle.trace_one(flat, tables, (0.25, 0.25, 1.0), (1.0, 0.0, 0.0))["hit"]    # parallel: det == 0
 
 
+def _tri_by_hand(v0, v1, v2, o, d, t_min=f32(0.001)):
+    """the triangle rule of rt_hip.h written out with numpy binary32 scalars:
+    -> (accepted by the barycentric test, accepted after the gate, t)"""
+    v0, v1, v2, o, d = [np.asarray(x, dtype=f32) for x in (v0, v1, v2, o, d)]
+    dot = lambda a, b: f32(f32(f32(a[0] * b[0]) + f32(a[1] * b[1])) + f32(a[2] * b[2]))
+    cross = lambda a, b: np.array([f32(f32(a[1] * b[2]) - f32(a[2] * b[1])), f32(f32(a[2] * b[0]) - f32(a[0] * b[2])),
+                                   f32(f32(a[0] * b[1]) - f32(a[1] * b[0]))], dtype=f32)
+    e1, e2 = v1 - v0, v2 - v0
+    h = cross(d, e2)
+    det = dot(e1, h)
+    if det == 0:
+        return False, False, None
+    f = f32(f32(1.0) / det)
+    s = o - v0
+    u = f32(f * dot(s, h))
+    if u < 0 or u > 1:
+        return False, False, None
+    q = cross(s, e1)
+    v = f32(f * dot(d, q))
+    if v < 0 or f32(u + v) > 1:
+        return False, False, None
+    t = f32(f * dot(e2, q))
+    if t < t_min:
+        return False, False, None
+    g = v0 + (e1 + e2) * f32(0.33333334)
+    m = max(dot(w, w) for w in (v0 - g, (v0 + e1) - g, (v0 + e2) - g))
+    r2 = f32(f32(m * f32(1.0078125)) + f32(dot(g, g) * f32(2.0 ** -30)))
+    w = (o + d * t) - g
+    return True, bool(dot(w, w) <= r2), t
+
+
+def test_triangle_vertices_and_edges_pass_the_gate(oracle, tables):
+    tri = Triangle((1.0, 2.0, -3.0), (2.5, 2.0, -3.5), (1.0, 3.25, -2.0), Lambertian((0.5, 0.5, 0.5)))
+    flat = one(tri)
+    for target in (tri.v0, tri.v1, tri.v2, (1.75, 2.0, -3.25), (1.75, 2.625, -2.75)):
+        o = (target[0] + 0.125, target[1] + 0.25, target[2] + 4.0)
+        d = (-0.125, -0.25, -4.0)
+        mt, gated, t = _tri_by_hand(tri.v0, tri.v1, tri.v2, o, d)
+        r = oracle.trace_one(flat, zero_screen(tables), o, d)
+        assert r["hit"] == gated and (not mt or gated)          # nothing on the triangle is cut
+        if gated:
+            assert r["t"] == t
+
+
+def test_triangle_gate_cuts_far_off_sliver_hits(oracle, tables):
+    """a needle seen from far away along its own line: the f32 barycentric test accepts
+    points many needle-lengths off its ends; the gate refuses them, and the oracle agrees
+    with the hand-written rule on every ray"""
+    rng = np.random.default_rng(42)
+    n_mt = n_cut = 0
+    for _ in range(4000):
+        v0 = rng.uniform(-1, 1, 3).astype(f32)
+        e = (rng.normal(size=3) * 0.002).astype(f32)
+        v1 = (v0 + e).astype(f32)
+        v2 = (v1 + e * f32(1e-4) + (rng.normal(size=3) * 2e-8)).astype(f32)
+        o = (v0 + rng.normal(size=3) * 20).astype(f32)
+        aim = v0 + e * f32(rng.uniform(-40, 40))             # a point on the needle's line, mostly off the needle
+        d = (aim - o).astype(f32)
+        mt, gated, t = _tri_by_hand(v0, v1, v2, o, d)
+        tri = Triangle(tuple(map(float, v0)), tuple(map(float, v1)), tuple(map(float, v2)), Lambertian((0.5, 0.5, 0.5)))
+        r = oracle.trace_one(one(tri), zero_screen(tables), tuple(map(float, o)), tuple(map(float, d)))
+        assert r["hit"] == gated
+        n_mt += mt
+        n_cut += mt and not gated
+    assert n_cut > 0, "no far-off acceptance in %d barycentric hits: the case is not exercised" % n_mt
+
+
 # ------------------------------------------------------------ sky, camera, quantiser
 def test_sky_gradient(oracle):
     """src/raytracer.rs:81-91: t = 0.5*unit.y + 1.0 (not 0.5*(y+1)); sqrt per channel"""

@@ -1,0 +1,100 @@
+"""Fuzz: the tree scan against the list-order scan of the same library on the GPU
+(RT_HIP_FLAT_SCAN=1 disables the tree; triangles then run their exact test one by one
+and spheres the rejection scan), over random scenes at frame sizes far beyond the CPU
+oracle.  Every output must be bit-identical.  usage: stress_tree_vs_list.py [seconds] [seed0]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from raytracing_amd import Camera, Renderer, flat_scene_from_arrays, load_tables, make_params  # noqa: E402
+
+
+def scene(rng):
+    style = rng.integers(0, 6)
+    n_s = int(rng.choice([0, 70, 300, 2000]))
+    n_t = int(rng.choice([0, 70, 500, 4000]))
+    if n_s + n_t == 0:
+        n_s = 500
+    ext = float(10.0 ** rng.uniform(-1, 3))            # scene extent 0.1 .. 1000
+    off = rng.uniform(-1, 1, 3) * ext * float(rng.choice([0, 0, 1, 100]))
+    c = (off + rng.uniform(-ext, ext, (n_s, 3))).astype(np.float32)
+    r = (ext * 10.0 ** rng.uniform(-3.5, -0.7, n_s)).astype(np.float32)
+    if style == 1:
+        r *= np.where(rng.random(n_s) < 0.2, -1, 1).astype(np.float32)
+    if style == 2 and n_s:                              # lattice: many exact ties and tangencies
+        g = np.stack(np.meshgrid(*[np.arange(13)] * 3), -1).reshape(-1, 3)[:n_s]
+        c = (off + (g - 6) * ext / 6).astype(np.float32)
+        r = np.full(n_s, ext / 12, dtype=np.float32)
+    v0 = (off + rng.uniform(-ext, ext, (n_t, 3))).astype(np.float32)
+    sz = (ext * 10.0 ** rng.uniform(-3, -0.3, (n_t, 1)))
+    v1 = (v0 + rng.normal(size=(n_t, 3)) * sz).astype(np.float32)
+    v2 = (v0 + rng.normal(size=(n_t, 3)) * sz).astype(np.float32)
+    if style == 3 and n_t:                              # slivers
+        v2 = (v1 + (v1 - v0) * 1e-4 + rng.normal(size=(n_t, 3)) * sz * 1e-5).astype(np.float32)
+    if style == 4 and n_t:                              # coplanar sheet: rays graze many at once
+        for v in (v0, v1, v2):
+            v[:, 1] = off[1]
+    n = n_s + n_t
+    kinds = rng.integers(0, 3, n).astype(np.int32)
+    order = rng.permutation(2) if n_s and n_t else [0, 1]
+    sid = np.arange(n_s) + (n_t if order[0] == 1 else 0)
+    tid = np.arange(n_t) + (n_s if order[0] == 0 else 0)
+    flat = flat_scene_from_arrays(
+        sph_cx=c[:, 0], sph_cy=c[:, 1], sph_cz=c[:, 2], sph_r=r, sph_mat=sid, sph_id=sid,
+        tri_v0x=v0[:, 0], tri_v0y=v0[:, 1], tri_v0z=v0[:, 2], tri_v1x=v1[:, 0], tri_v1y=v1[:, 1], tri_v1z=v1[:, 2],
+        tri_v2x=v2[:, 0], tri_v2y=v2[:, 1], tri_v2z=v2[:, 2], tri_mat=tid, tri_id=tid,
+        mat_kind=kinds, mat_r=rng.uniform(0.2, 1, n), mat_g=rng.uniform(0.2, 1, n), mat_b=rng.uniform(0.2, 1, n),
+        mat_param=np.where(kinds == 2, 1.5, rng.uniform(0, 0.4, n)))
+    where = rng.integers(0, 3)
+    origin = off + (rng.uniform(-1, 1, 3) * ext * (0.3 if where == 0 else 2.5 if where == 1 else 30.0))
+    if style == 4:
+        origin[1] = off[1] + ext * float(rng.choice([0.0, 1e-3, 0.2]))      # in or just above the sheet
+    look = off + rng.uniform(-0.3, 0.3, 3) * ext
+    cam = Camera.new(float(rng.uniform(5, 100)), 16 / 9, float(rng.choice([0, 0.05 * ext])),
+                     float(np.linalg.norm(origin - look)) + 1e-3, tuple(origin), tuple(look), (0.0, 1.0, 0.0))
+    return flat, cam
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    r = Renderer(0, load_tables())
+    t0 = time.time()
+    k = 0
+    rays = 0
+    bad = 0
+    while time.time() - t0 < budget:
+        rng = np.random.default_rng(seed0 + k)
+        flat, cam = scene(rng)
+        p = make_params(1280, 720, spp=2, seed=k)
+        out = []
+        for mode in ("tree", "list"):
+            if mode == "list":
+                os.environ["RT_HIP_FLAT_SCAN"] = "1"
+            try:
+                r.set_scene(flat)
+            finally:
+                os.environ.pop("RT_HIP_FLAT_SCAN", None)
+            r.set_camera(cam)
+            r.begin_frame(p.width, p.height)
+            r.render(p)
+            out.append((r.read_accum().view(np.uint32), r.read_primary_ids(), r.ray_count()))
+        same = np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+        rays += out[0][2]
+        if not same:
+            bad += 1
+            d = (out[0][0] != out[1][0]).any(-1)
+            print("MISMATCH seed", seed0 + k, "pixels", int(d.sum()), "ids", int((out[0][1] != out[1][1]).sum()),
+                  "segments", out[0][2], out[1][2], flush=True)
+        k += 1
+        if k % 10 == 0:
+            print("scenes", k, "segments %.3g" % rays, "mismatches", bad, "t %.0f s" % (time.time() - t0), flush=True)
+    print("DONE scenes", k, "segments %.4g" % rays, "mismatches", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
