@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -38,6 +39,7 @@ struct Ctx {
     float4 *d_accum = nullptr;
     uint32_t *d_packed = nullptr;
     int32_t *d_ids = nullptr;
+    float4 *d_samples = nullptr;   // DEV_SAMPLE_CHUNK colour planes, see DevFrame::samples
     unsigned long long *d_segments = nullptr;
     bool have_frame = false;
 };
@@ -69,7 +71,8 @@ void free_frame(Ctx *c) {
     if (c->d_accum) (void)hipFree(c->d_accum);
     if (c->d_packed) (void)hipFree(c->d_packed);
     if (c->d_ids) (void)hipFree(c->d_ids);
-    c->d_accum = nullptr; c->d_packed = nullptr; c->d_ids = nullptr;
+    if (c->d_samples) (void)hipFree(c->d_samples);
+    c->d_accum = nullptr; c->d_packed = nullptr; c->d_ids = nullptr; c->d_samples = nullptr;
     c->have_frame = false;
     c->W = c->H = 0;
 }
@@ -227,6 +230,7 @@ int rt_begin_frame(rt_ctx *ctx, uint32_t width, uint32_t height) {
         HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_accum), n_px * sizeof(float4)));
         HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_packed), n_px * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_ids), n_px * sizeof(int32_t)));
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_samples), n_px * DEV_SAMPLE_CHUNK * sizeof(float4)));
         c->W = width; c->H = height;
         c->have_frame = true;
     }
@@ -256,8 +260,15 @@ int rt_render(rt_ctx *ctx, const rt_params *p) {
     if (n_bands == 0 || p->sample_count == 0) return RT_OK;
     if (n_bands > 65535u) return fail(c, RT_E_BADARG, "rt_render: too many bands for one launch");
     HIP_TRY(c, hipSetDevice(c->device));
-    DevFrame fr{c->d_disc, c->d_sphere, c->d_screen, c->d_accum, c->d_ids, c->d_segments};
-    HIP_TRY(c, rtk_launch_render(c->dsc, c->cam, *p, fr, n_bands, c->stream));
+    DevFrame fr{c->d_disc, c->d_sphere, c->d_screen, c->d_accum, c->d_ids, c->d_samples, c->d_segments};
+    // one launch per DEV_SAMPLE_CHUNK samples: the per-sample colours of a launch are staged
+    // in d_samples before they are added to the sums in sample order
+    rt_params part = *p;
+    for (uint32_t done = 0; done < p->sample_count; done += DEV_SAMPLE_CHUNK) {
+        part.sample_begin = p->sample_begin + done;
+        part.sample_count = std::min(DEV_SAMPLE_CHUNK, p->sample_count - done);
+        HIP_TRY(c, rtk_launch_render(c->dsc, c->cam, part, fr, n_bands, c->stream));
+    }
     return RT_OK;
 }
 

@@ -66,6 +66,7 @@ struct DevScene {
     uint32_t lds_run, lds_level, lds_first_step, lds_steps;
     uint32_t modes;           // bit 0: some run is RUN_FLAT, bit 1: some run is RUN_TREE
 };
+#define DEV_SAMPLE_CHUNK 32u     // samples per pixel one launch renders at most (sizes DevFrame::samples)
 #define DEV_TREE_LDS_STEPS 192u   // 30 KB of tree per workgroup
 
 // Per-frame buffers and the lookup tables
@@ -75,6 +76,7 @@ struct DevFrame {
     const float *tbl_screen;  // 16384
     float4 *accum;            // {r,g,b,n} per pixel, display order
     int32_t *primary_ids;     // per pixel, display order
+    float4 *samples;          // colour of sample k of this launch at [k * width*height + pixel]
     unsigned long long *segments;
 };
 

@@ -153,6 +153,7 @@ struct Lds {
     float sphere[768];                                  // src/denoising/mod.rs:59
     uint32_t mat_stack[waves_of(MODES)][RT_MAX_BOUNCES][64];
     TreeTable tree[waves_of(MODES)];                    // per-level constants of the run being walked
+    uint32_t next_item;                                 // work items handed out so far
     f4 tree_top[(MODES & 2) ? DEV_TREE_LDS_STEPS * 10 : 1];   // top levels of one tree (DevScene::lds_*)
 };
 
@@ -765,6 +766,7 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
     const SceneView sc = view_of(dsc, fr.segments);
     for (uint32_t k = threadIdx.x; k < 128; k += blockDim.x) lds.disc[k] = fr.tbl_disc[k];
     for (uint32_t k = threadIdx.x; k < 768; k += blockDim.x) lds.sphere[k] = fr.tbl_sphere[k];
+    if (threadIdx.x == 0) lds.next_item = 0u;
     if (MODES & 2) {
         const RT_CONST_AS f4 *src = sc.tree_rec + 10u * (size_t)dsc.lds_first_step;
         for (uint32_t k = threadIdx.x; k < dsc.lds_steps * 10u; k += blockDim.x) lds.tree_top[k] = src[k];
@@ -774,37 +776,34 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t W = p.width, H = p.height;
     const uint32_t band = p.band_begin + blockIdx.y * p.band_stride;
-    const uint32_t i = (blockIdx.x * waves_of(MODES) + wave) * TILE + (lane & 7u);     // column
-    const uint32_t j = band * TILE + (lane >> 3);                                    // row from the bottom
-    const bool inside = i < W && j < H;
-    const uint32_t row = H - 1u - j;                                                 // src/raytracer.rs:265
-    const size_t pix_out = (size_t)row * W + i;
-    const uint32_t pix = j * W + i;
-    const uint32_t s_end = p.sample_begin + p.sample_count;
+    const uint32_t x0 = blockIdx.x * waves_of(MODES) * TILE, y0 = band * TILE;   // the workgroup's strip of tiles
     const bool gamma = p.gamma != 0;
+    const size_t n_px = (size_t)W * H;
 
+    // Work items: (pixel of the strip, sample), sample-major, handed out through one counter
+    // per workgroup, so a lane whose path ends takes the next item whatever pixel it belongs
+    // to.  Pixels differ a lot in segments per sample; with one lane per pixel the wave would
+    // wait for its slowest pixel.  The colour of every sample goes to fr.samples and is added
+    // to the pixel's sum in sample order at the end (the sums must not depend on which lane
+    // finished first: `px_colour += ...`, src/raytracer.rs:262, is an ordered f32 sum).
+    const uint32_t strip_px = waves_of(MODES) * 64u;
+    const uint32_t n_items = strip_px * p.sample_count;
+
+    uint32_t q = 0, s = 0, i = 0, j = 0;   // this lane's item: pixel of the strip, sample, column, row from the bottom
     float sp_bn = 0.0f;
-    V3 px = mk(0.0f, 0.0f, 0.0f);
-    float n_prev = 0.0f;
-    if (inside) {
-        // BlueNoise::get_screenspace, src/denoising/mod.rs:19-23: fixed per pixel
-        sp_bn = fr.tbl_screen[128u * (i % 128u) + (j % 128u)];
-        float4 acc = fr.accum[pix_out];
-        px = mk(acc.x, acc.y, acc.z);
-        n_prev = acc.w;
-    }
-
-    uint32_t s = p.sample_begin;
-    bool alive = inside && p.sample_count > 0 && p.max_bounces > 0;
+    bool alive = false;
     Ray ray;
     ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1);
     uint32_t depth_left = p.max_bounces, n_stack = 0, path_key = 0, path_counter = 0;
     uint32_t n_seg = 0;
 
     auto start_sample = [&]() {
+        // BlueNoise::get_screenspace, src/denoising/mod.rs:19-23: fixed per pixel
+        sp_bn = fr.tbl_screen[128u * (i % 128u) + (j % 128u)];
         // two disc draws per sample: jitter then lens (src/raytracer.rs:254,258);
         // sample n of a single-thread run uses entries 2n+1 and 2n+2 of the
         // pre-incremented counter (src/denoising/mod.rs:13-17)
+        const uint32_t pix = j * W + i;
         uint32_t n = pix * p.spp + s;   // only n mod 32 matters, wrap is harmless
         uint32_t k1 = (2u * n + 1u) & 63u, k2 = (2u * n + 2u) & 63u;
         float ox = lds.disc[2 * k1], oy = lds.disc[2 * k1 + 1];
@@ -817,15 +816,37 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
         depth_left = p.max_bounces;
         n_stack = 0;
     };
-    if (alive) start_sample();
+    // lanes with `need` take the next items; lanes left without one stay idle for good
+    auto fetch = [&](bool need) {
+        for (;;) {
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(need);
+            if (mask == 0ull) break;
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(mask);
+            uint32_t base = 0;
+            if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(&lds.next_item, cnt);
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(mask));
+            if (base >= n_items) break;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            const uint32_t k = base + rank;
+            if (need && k < n_items) {
+                q = k % strip_px;
+                s = p.sample_begin + k / strip_px;
+                i = x0 + (q >> 6) * TILE + (q & 7u);
+                j = y0 + ((q >> 3) & 7u);
+                if (i < W && j < H) { start_sample(); need = false; alive = true; }
+            }
+        }
+    };
+    if (p.max_bounces > 0) fetch(true);
 
     while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
         Hit h;
         scan_list<MODES>(sc, ray, p.t_min, alive, lds.tree[wave], lds.tree_top, h);
         n_seg += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(alive));
+        bool done = false;
         if (alive) {
+            const size_t pix_out = (size_t)(H - 1u - j) * W + i;   // src/raytracer.rs:265
             if (s == 0u && n_stack == 0u) fr.primary_ids[pix_out] = h.id;
-            bool done;
             V3 c;
             if (h.kind >= 0) {
                 uint32_t bounce = p.max_bounces - depth_left;
@@ -845,16 +866,30 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
                     const f4 ma = sc.mat_albedo[lds.mat_stack[wave][k][lane]];
                     c = mk(ma.x, ma.y, ma.z) * c;
                 }
-                px = px + c;   // src/raytracer.rs:262
-                s += 1;
-                if (s < s_end) start_sample();
-                else alive = false;
+                fr.samples[(size_t)(s - p.sample_begin) * n_px + pix_out] = make_float4(c.x, c.y, c.z, 0.0f);
+                alive = false;
             }
         }
+        if (__builtin_amdgcn_ballot_w64(done) != 0ull) fetch(done);
     }
 
-    if (inside) {
-        fr.accum[pix_out] = make_float4(px.x, px.y, px.z, n_prev + (float)p.sample_count);
+    // every sample of the strip is in memory once all waves are here; each thread then adds
+    // up its own pixel in sample order
+    __threadfence();
+    __syncthreads();
+    {
+        const uint32_t pi = x0 + wave * TILE + (lane & 7u), pj = y0 + (lane >> 3);
+        if (pi < W && pj < H) {
+            const size_t pix_out = (size_t)(H - 1u - pj) * W + pi;
+            float4 acc = fr.accum[pix_out];
+            V3 px = mk(acc.x, acc.y, acc.z);
+            // with a depth budget of 0 every sample is black and nothing was traced
+            for (uint32_t k = 0; k < (p.max_bounces > 0 ? p.sample_count : 0u); ++k) {
+                const float4 c = fr.samples[(size_t)k * n_px + pix_out];
+                px = px + mk(c.x, c.y, c.z);   // src/raytracer.rs:262
+            }
+            fr.accum[pix_out] = make_float4(px.x, px.y, px.z, acc.w + (float)p.sample_count);
+        }
     }
     if (lane == 0 && n_seg != 0) atomicAdd(fr.segments, (unsigned long long)n_seg);
 }
