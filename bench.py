@@ -111,10 +111,10 @@ def hbm_traffic_from_profile(workload):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c4")
-    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--spp-per-step", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-flat-probe", action="store_true")
     args = ap.parse_args()

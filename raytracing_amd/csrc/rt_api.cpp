@@ -188,7 +188,7 @@ int rt_upload_scene(rt_ctx *ctx, const rt_scene *s) {
     d.n_runs = (uint32_t)hs.runs.size();
     d.need_ff_shared = hs.need_ff_shared;
     d.lds_run = hs.lds_run; d.lds_level = hs.lds_level;
-    d.lds_first_step = hs.lds_first_step; d.lds_steps = hs.lds_steps;
+    d.lds_first = hs.lds_first; d.lds_count = hs.lds_count;
     d.modes = hs.modes;
     if ((rc = upload(c, hs.runs, &d.runs)) != RT_OK || (rc = upload(c, hs.sph_geom, &d.sph_geom)) != RT_OK ||
         (rc = upload(c, hs.sph_mat, &d.sph_mat)) != RT_OK || (rc = upload(c, hs.sph_id, &d.sph_id)) != RT_OK ||

@@ -85,11 +85,11 @@ struct SceneView {
     const RT_CONST_AS u16v *runs;         // two per DevRun
     const RT_CONST_AS f4 *sph_geom, *planes, *cubes, *tris, *mat_albedo;
     const RT_CONST_AS f16 *cull_rec;      // RUN_FLAT: two per step of eight records
-    const RT_CONST_AS f4 *tree_rec;       // RUN_TREE: ten per step of eight records
+    const RT_CONST_AS f4 *tree_rec;       // RUN_TREE: ten per step of eight balls, twelve per step of eight boxes
     const RT_CONST_AS uint32_t *sph_mat, *sph_id, *tri_id, *order;
     const RT_CONST_AS int32_t *mat_kind;
     uint32_t n_runs, need_ff_shared;
-    uint32_t lds_run, lds_level, lds_first_step;
+    uint32_t lds_run, lds_level, lds_first;
     unsigned long long *stats;   // fr.segments; slots 1..7 are instrumentation (RTK_STATS builds)
 };
 __device__ __forceinline__ SceneView view_of(const DevScene &sc, unsigned long long *stats) {
@@ -110,7 +110,7 @@ __device__ __forceinline__ SceneView view_of(const DevScene &sc, unsigned long l
     v.mat_kind = const_ptr<int32_t>(sc.mat_kind);
     v.n_runs = sc.n_runs;
     v.need_ff_shared = sc.need_ff_shared;
-    v.lds_run = sc.lds_run; v.lds_level = sc.lds_level; v.lds_first_step = sc.lds_first_step;
+    v.lds_run = sc.lds_run; v.lds_level = sc.lds_level; v.lds_first = sc.lds_first;
     return v;
 }
 // the words of a DevRun as the two scalar loads deliver them
@@ -118,7 +118,7 @@ struct RunView {
     uint32_t kind, first, count, id0, mode, n_levels, top_steps, order_base;
     u16v lo, hi;
     __device__ __forceinline__ uint32_t level_base(uint32_t L) const { return lo[8 + L]; }
-    __device__ __forceinline__ float level_keep(uint32_t L) const { return __uint_as_float(hi[L]); }
+    __device__ __forceinline__ float level_keep(uint32_t L) const { return __uint_as_float(hi[L]); }   // ball levels only
 };
 __device__ __forceinline__ RunView load_run(const SceneView &sc, uint32_t r) {
     RunView v;
@@ -134,8 +134,8 @@ __host__ __device__ constexpr int waves_of(int modes) { return (modes & 2) ? RTK
 constexpr int TILE = 8;   // 8x8 pixels per wavefront
 
 struct TreeTable {
-    uint32_t base[DEV_MAX_LEVELS];
-    float keep[DEV_MAX_LEVELS];
+    uint32_t base[DEV_MAX_LEVELS];    // float4 offset of each level in tree_rec
+    uint32_t count[DEV_MAX_LEVELS];   // boxes at each level above the leaves
     // closest-hit state of every lane when it entered the run being walked, for the lanes
     // that have to start the run over in list order
     float entry_t[64];
@@ -154,7 +154,7 @@ struct Lds {
     uint32_t mat_stack[waves_of(MODES)][RT_MAX_BOUNCES][64];
     TreeTable tree[waves_of(MODES)];                    // per-level constants of the run being walked
     uint32_t next_item;                                 // work items handed out so far
-    f4 tree_top[(MODES & 2) ? DEV_TREE_LDS_STEPS * 10 : 1];   // top levels of one tree (DevScene::lds_*)
+    f4 tree_top[(MODES & 2) ? DEV_TREE_LDS_F4 : 1];     // top levels of one tree (DevScene::lds_*)
 };
 
 struct Ray { V3 o, d; };
@@ -194,8 +194,16 @@ __device__ __forceinline__ float powi5(float x) { float x2 = x * x; float x4 = x
         if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u)       \
             atomicAdd((sc).stats + (slot), n_);                                             \
     } while (0)
+// the same from divergent code: counted once per wave by its first active lane
+#define RTK_COUNT_ANY(sc, slot, n)                                                          \
+    do {                                                                                    \
+        unsigned long long n_ = (unsigned long long)(n);                                    \
+        if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) \
+            atomicAdd((sc).stats + (slot), n_);                                             \
+    } while (0)
 #else
 #define RTK_COUNT(sc, slot, n) do { } while (0)
+#define RTK_COUNT_ANY(sc, slot, n) do { } while (0)
 #endif
 
 struct Hit {
@@ -403,20 +411,35 @@ __device__ __forceinline__ void scan_flat(const SceneView &sc, const RunView &ru
 }
 
 // ----------------------------------------------------------------------
-// RUN_TREE: the run's primitives are stored in a spatially hierarchical order; level 0 of the
-// implicit 8-ary tree holds their own balls, level L+1 one ball per step of
-// level L (children of step s at level L+1 ... are the steps 8s..8s+7 one level
-// down).  Every lane walks the tree for its own ray: per trip each lane with
-// work left fetches ITS node (ten 16-byte loads, 160 bytes), tests the eight
-// child balls, and either descends, runs the exact test on surviving
-// primitives (level 0), or moves on to the next pending sibling.  No stack:
-// the path is the step index itself (parent = s >> 3), the children still to
-// visit are one byte per level in a 64-bit register.  The wave loops until a
-// ballot says no lane has a node left.
+// RUN_TREE: the run's primitives are stored in a spatially hierarchical order under an
+// implicit 8-ary tree.  Level 0 holds their own ball records in steps of eight, level L+1
+// one bounding box per step of level L (the children of step s of level L+1 are the steps
+// 8s..8s+7 one level down).  Every lane walks the tree for its own ray.  No stack: the path
+// is the step index itself (parent = s >> 3), the children still to visit are one byte per
+// level in a 64-bit register.
 //
-// A child ball is skipped when the RAY (not the line) cannot touch it:
+// The wave alternates between two loops so that each runs one kind of node for all its
+// lanes: the box loop, in which every lane that stands on a box node fetches ITS node
+// (192 bytes), tests the eight child boxes and descends into the nearest survivor, until no
+// lane stands on a box node; then one leaf step, in which every lane that has reached a
+// leaf step tests its eight balls, runs the exact test on the survivors, and moves on to its
+// next pending node.  The walk ends when a ballot says no lane has a node left.
+//
+// A child box [lo, hi] is skipped when the ray misses the box widened by `pad` on every
+// side, lies behind the origin, or starts beyond closest_so_far (slab test:
+// t = (plane - o) / d per axis, with 1/d and the offsets folded into one FMA per plane).
+// `pad` covers (a) how far the reference's f32 arithmetic lets a primitive reach beyond its
+// geometric extent and (b) the rounding of the slab test, both proportional to
+// S = |o| + reach >= |o - x| for every point x of the run:
+//   (a) spheres: the discriminant of Sphere::hit is uncertain by kappa a |o-c|^2 with
+//       kappa < 2^-19, so a root lies up to sqrt(r^2 + kappa |o-c|^2) from the centre:
+//       at most min(sqrt(kappa) S, kappa S^2 / (2 r_min)) beyond r;
+//       triangles: the gate ball is exact, the hit point o + t*d is off by < 4 ulp S;
+//   (b) each t is off by a few ulp of (|plane| + |o| + pad) |1/d|, i.e. the plane by a few
+//       ulp of S: 2^-18 S covers (b) and the triangles' (a).
+// A ball of the leaf level is skipped when
 //   |o|^2 keep - 2 o.c - max((c-o).u, 0)^2 > thr          (misses sideways / lies behind)
-//   (c-o).u - R > closest_so_far * |d| (+ rounding slack)  (lies beyond the best hit)
+//   (c-o).u - R > closest_so_far * |d| + slack             (lies beyond the best hit)
 // A lane leaves the walk as soon as its closest_so_far turns NaN (see scan_tree).
 // ----------------------------------------------------------------------
 template <int KIND>
@@ -425,50 +448,122 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
                                           const Ray &ray, float a, float t_min, Hit &h, bool &ff_shared) {
     // per-level constants where a lane can index them by its own level
 #pragma unroll
-    for (uint32_t L = 0; L < DEV_MAX_LEVELS; ++L) { tbl.base[L] = run.lo[8 + L]; tbl.keep[L] = __uint_as_float(run.hi[L]); }
+    for (uint32_t L = 0; L < DEV_MAX_LEVELS; ++L) { tbl.base[L] = run.lo[8 + L]; tbl.count[L] = run.hi[L]; }
     const float len = __builtin_sqrtf(a);
-    // Slack of the "beyond the best hit" test.  (c-o).u and the reference's root are off by
-    // < 10 ulp (|o|+|c|): 2^-20 S with S = |o| + reach >= |o-c| for every ball of the run.
-    // For spheres the f32 discriminant of Sphere::hit is uncertain by kappa a |o-c|^2 with
-    // kappa < 2^-19, so the root it yields lies on a sphere of radius sqrt(r^2 + kappa |o-c|^2)
-    // around the centre rather than r: up to min(sqrt(kappa) S, kappa S^2 / (2 r_min)) further
-    // out than any bounding ball accounts for.
     const float S = __builtin_sqrtf(cull.oo) + __uint_as_float(run.hi[8]);
-    float far_pad = S * (1.0f / 1048576.0f);
+    float reach_pad = 0.0f;
     if (KIND == DEV_SPHERE) {
         const float kS = S * (1.0f / 524288.0f);
-        far_pad += __builtin_fminf(S * 1.3811e-3f, kS * S * __uint_as_float(run.hi[9]));
+        reach_pad = __builtin_fminf(S * 1.3811e-3f, kS * S * __uint_as_float(run.hi[9]));
     }
+    const float far_pad = S * (1.0f / 1048576.0f) + reach_pad;        // leaf level, a length
     const float far_len = len * (1.0f + 1.0f / 1048576.0f);
+    const float pad = S * (1.0f / 262144.0f) + reach_pad;             // box levels
+    // slab test constants: t = plane * inv + k, k = -(o -+ pad) * inv
+    // 1/d clamped to +-1e19: a zero component would make plane * inv and k infinities of
+    // opposite sign.  With |d| in (1e-6, 1e6) (see scan_tree) a component below 1e-19 moves
+    // the ray by less than 2e-13 S over any distance that matters, far inside the pad.
+    const float ix = __builtin_fminf(__builtin_fmaxf(1.0f / ray.d.x, -1e19f), 1e19f);
+    const float iy = __builtin_fminf(__builtin_fmaxf(1.0f / ray.d.y, -1e19f), 1e19f);
+    const float iz = __builtin_fminf(__builtin_fmaxf(1.0f / ray.d.z, -1e19f), 1e19f);
+    const float klx = -((ray.o.x + pad) * ix), kly = -((ray.o.y + pad) * iy), klz = -((ray.o.z + pad) * iz);
+    const float khx = -((ray.o.x - pad) * ix), khy = -((ray.o.y - pad) * iy), khz = -((ray.o.z - pad) * iz);
+    const float oo_keep = cull.oo * __uint_as_float(run.hi[0]);
     const uint32_t top = run.n_levels - 1u;
+    const uint32_t base0 = run.lo[8];
     const RT_CONST_AS f4 *nodes = sc.tree_rec;
 
     for (uint32_t ts = 0; ts < run.top_steps; ++ts) {
         uint32_t L = top, st = ts;
         unsigned long long pend = 0ull;
         bool act = walking;
+        // next pending sibling, of this node or of its nearest ancestor that has one
+        auto next_pending = [&]() {
+            const unsigned long long rest = pend >> (8u * L);
+            if (rest == 0ull || h.t != h.t) {
+                act = false;
+            } else {
+                const uint32_t z = (uint32_t)__builtin_ctzll(rest);
+                const uint32_t up = z >> 3, k = z & 7u;
+                L += up;
+                st = ((st >> (3u * up)) & ~7u) | k;
+                pend &= ~(1ull << (8u * L + k));
+            }
+        };
         while (__builtin_amdgcn_ballot_w64(act) != 0ull) {
-            RTK_COUNT(sc, 2, 1);
-            RTK_COUNT(sc, 5, __builtin_popcountll(__builtin_amdgcn_ballot_w64(act)));
-            RTK_COUNT(sc, 6, __builtin_popcountll(__builtin_amdgcn_ballot_w64(act && L == 0u)));
-            if (act) {
-                // the node's 160 bytes: from the workgroup's LDS copy for the top levels of the
-                // cached tree, from global memory (L1/L2) otherwise
-                const uint32_t step = tbl.base[L] + st;
-                f4 nd[10];
-                if (L >= lds_from_level) {
-                    const f4 *src = tree_top + 10u * (step - sc.lds_first_step);
+            // ---- box nodes
+            while (__builtin_amdgcn_ballot_w64(act && L != 0u) != 0ull) {
+                RTK_COUNT(sc, 2, 1);
+                RTK_COUNT(sc, 5, __builtin_popcountll(__builtin_amdgcn_ballot_w64(act && L != 0u)));
+                if (act && L != 0u) {
+                    const uint32_t at = tbl.base[L] + 12u * st;
+                    f4 nd[12];
+                    if (L >= lds_from_level) {
+                        const f4 *src = tree_top + (at - sc.lds_first);
 #pragma unroll
-                    for (int q = 0; q < 10; ++q) nd[q] = src[q];
-                } else {
-                    const RT_CONST_AS f4 *src = nodes + 10u * (size_t)step;
+                        for (int q = 0; q < 12; ++q) nd[q] = src[q];
+                    } else {
+                        const RT_CONST_AS f4 *src = nodes + (size_t)at;
 #pragma unroll
-                    for (int q = 0; q < 10; ++q) nd[q] = src[q];
+                        for (int q = 0; q < 12; ++q) nd[q] = src[q];
+                    }
+                    uint32_t sign_bits = 0u;
+                    uint32_t nearest = 0xffffffffu;   // min over surviving children of (entry distance | index)
+#pragma unroll
+                    for (int pr = 0; pr < 4; ++pr) {
+                        const f4 X = nd[3 * pr], Y = nd[3 * pr + 1], Z = nd[3 * pr + 2];   // lo0, lo1, hi0, hi1
+                        const f2 ix2 = {ix, ix}, iy2 = {iy, iy}, iz2 = {iz, iz};
+                        const f2 tlx = __builtin_elementwise_fma(X.xy, ix2, (f2){klx, klx}), thx = __builtin_elementwise_fma(X.zw, ix2, (f2){khx, khx});
+                        const f2 tly = __builtin_elementwise_fma(Y.xy, iy2, (f2){kly, kly}), thy = __builtin_elementwise_fma(Y.zw, iy2, (f2){khy, khy});
+                        const f2 tlz = __builtin_elementwise_fma(Z.xy, iz2, (f2){klz, klz}), thz = __builtin_elementwise_fma(Z.zw, iz2, (f2){khz, khz});
+                        float tn[2], nn[2];
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const float ax_ = c ? tlx.y : tlx.x, bx_ = c ? thx.y : thx.x;
+                            const float ay_ = c ? tly.y : tly.x, by_ = c ? thy.y : thy.x;
+                            const float az_ = c ? tlz.y : tlz.x, bz_ = c ? thz.y : thz.x;
+                            const float enter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax_, bx_), __builtin_fminf(ay_, by_)),
+                                                                __builtin_fmaxf(__builtin_fminf(az_, bz_), 0.0f));
+                            const float leave = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax_, bx_), __builtin_fmaxf(ay_, by_)),
+                                                                __builtin_fminf(__builtin_fmaxf(az_, bz_), h.t));
+                            tn[c] = enter;
+                            nn[c] = leave - enter;   // >= 0: some point of the ray in front of the best hit is inside
+                        }
+                        sign_bits |= (__float_as_uint(nn[0]) >> 31) << (2 * pr);
+                        sign_bits |= (__float_as_uint(nn[1]) >> 31) << (2 * pr + 1);
+                        // enter >= 0 orders like its bit pattern; the low three bits carry the child
+                        // index, a rejected child becomes all ones
+                        const uint32_t kx = ((__float_as_uint(tn[0]) & ~7u) | (uint32_t)(2 * pr)) | (uint32_t)((int32_t)__float_as_uint(nn[0]) >> 31);
+                        const uint32_t ky = ((__float_as_uint(tn[1]) & ~7u) | (uint32_t)(2 * pr + 1)) | (uint32_t)((int32_t)__float_as_uint(nn[1]) >> 31);
+                        nearest = min(nearest, min(kx, ky));
+                    }
+                    // children past the end of the level below do not exist
+                    const uint32_t have = min(8u, tbl.count[L] - 8u * st);
+                    const uint32_t bits = ~sign_bits & ((1u << have) - 1u);
+                    if (bits != 0u) {
+                        // descend into the surviving child the ray enters first (so that a near
+                        // hit bounds the rest of the walk early), remember the others
+                        uint32_t k = nearest & 7u;
+                        if (((bits >> k) & 1u) == 0u) k = (uint32_t)__builtin_ctz(bits);   // nearest was a masked-out child
+                        L -= 1u;
+                        pend |= (unsigned long long)(bits & ~(1u << k)) << (8u * L);
+                        st = 8u * st + k;
+                    } else {
+                        next_pending();
+                    }
                 }
-                const float oo_keep = cull.oo * tbl.keep[L];
+            }
+            // ---- one leaf step for every lane that stands on one
+            if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
+            RTK_COUNT(sc, 3, 1);
+            RTK_COUNT(sc, 6, __builtin_popcountll(__builtin_amdgcn_ballot_w64(act)));
+            if (act) {
+                const RT_CONST_AS f4 *src = nodes + (size_t)(base0 + 10u * st);
+                f4 nd[10];
+#pragma unroll
+                for (int q = 0; q < 10; ++q) nd[q] = src[q];
                 const float tl = __builtin_fmaf(h.t, far_len, far_pad);   // inf while nothing is hit
                 uint32_t sign_bits = 0u;
-                uint32_t nearest = 0xffffffffu;   // min over surviving children of (distance along the ray | index)
 #pragma unroll
                 for (int pr = 0; pr < 4; ++pr) {
                     const f4 A = nd[pr];          // cx0, cx1, cy0, cy1
@@ -485,51 +580,25 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
                     const f2 g = __builtin_elementwise_fma(-mp, mp, w);
                     const f2 n1 = B.zw - g;             // >= 0: the ray passes within reach sideways
                     const f2 n2 = (tl2 + rr) - m;       // >= 0: the ball starts before the best hit
-                    // a child survives unless one of the two is negative; collect the sign bits
                     const float nx = __builtin_fminf(n1.x, n2.x), ny = __builtin_fminf(n1.y, n2.y);
                     sign_bits |= (__float_as_uint(nx) >> 31) << (2 * pr);
                     sign_bits |= (__float_as_uint(ny) >> 31) << (2 * pr + 1);
-                    // max(m,0) >= 0 orders like its bit pattern; the low three bits carry the child
-                    // index, a rejected child becomes all ones
-                    const uint32_t kx = ((__float_as_uint(mp.x) & ~7u) | (uint32_t)(2 * pr)) | (uint32_t)((int32_t)__float_as_uint(nx) >> 31);
-                    const uint32_t ky = ((__float_as_uint(mp.y) & ~7u) | (uint32_t)(2 * pr + 1)) | (uint32_t)((int32_t)__float_as_uint(ny) >> 31);
-                    nearest = min(nearest, min(kx, ky));
                 }
+                // exact test of the primitives this lane could not reject, in slot order
                 uint32_t bits = ~sign_bits & 0xffu;
-                if (L == 0u) {
-                    // exact test of the primitives this lane could not reject, in slot order
-                    while (bits != 0u) {
-                        const uint32_t k = (uint32_t)__builtin_ctz(bits);
-                        bits &= bits - 1u;
-                        const uint32_t idx = 8u * st + k;
-                        if (idx < run.count) {
-                            RTK_COUNT(sc, 4, 1);
-                            const uint32_t slot = run.first + idx;
-                            if (KIND == DEV_SPHERE) sphere_exact(sc, slot, (int32_t)sc.sph_id[slot], ray, a, t_min, h, ff_shared);
-                            else tri_exact(sc, slot, (int32_t)sc.tri_id[slot], ray, t_min, h, ff_shared);
-                        }
+                while (bits != 0u) {
+                    const uint32_t k = (uint32_t)__builtin_ctz(bits);
+                    bits &= bits - 1u;
+                    const uint32_t idx = 8u * st + k;
+                    if (idx < run.count) {
+                        RTK_COUNT(sc, 4, 1);
+                        RTK_COUNT_ANY(sc, 7, 1);
+                        const uint32_t slot = run.first + idx;
+                        if (KIND == DEV_SPHERE) sphere_exact(sc, slot, (int32_t)sc.sph_id[slot], ray, a, t_min, h, ff_shared);
+                        else tri_exact(sc, slot, (int32_t)sc.tri_id[slot], ray, t_min, h, ff_shared);
                     }
                 }
-                if (L != 0u && bits != 0u) {
-                    // descend into the surviving child whose ball comes first along the ray (so
-                    // that a near hit bounds the rest of the walk early), remember the others
-                    const uint32_t k = nearest & 7u;
-                    L -= 1u;
-                    pend |= (unsigned long long)(bits & ~(1u << k)) << (8u * L);
-                    st = 8u * st + k;
-                } else {
-                    // next pending sibling, of this node or of its nearest ancestor that has one
-                    const unsigned long long rest = pend >> (8u * L);
-                    if (rest == 0ull || h.t != h.t) {
-                        act = false;
-                    } else {
-                        const uint32_t z = (uint32_t)__builtin_ctzll(rest);
-                        const uint32_t up = z >> 3, k = z & 7u;
-                        L += up;
-                        st = ((st >> (3u * up)) & ~7u) | k;
-                        pend &= ~(1ull << (8u * L + k));
-                    }
-                }
+                next_pending();
             }
         }
     }
@@ -540,8 +609,8 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
 // The reference's result depends on the visiting order only while a hit
 // distance is NaN (src/geometry/mod.rs:74: both comparisons fail and the
 // sphere is accepted, whatever is held).  Rays that enter with such numbers
-// (zero or non-finite direction, NaN closest_so_far inherited from an earlier
-// run, huge origins) are kept out of the walk; a lane whose closest_so_far
+// (non-finite direction or one outside 1e-6 .. 1e6 in length, NaN closest_so_far
+// inherited from an earlier run, huge origins) are kept out of the walk; a lane whose closest_so_far
 // turns NaN during the walk (a primitive with NaN/overflowing coordinates, a
 // triangle whose determinant underflows) drops out of it.  Both kinds then
 // take the run in list order, the second from the state it entered with.
@@ -552,7 +621,7 @@ __device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &ru
                                           const Ray &ray, float a, float t_min, Hit &h, bool &ff_shared) {
     const float big = 1e18f;
     const uint32_t lane = threadIdx.x & 63u;
-    const bool tame = a > 1e-30f && a < big && h.t == h.t &&
+    const bool tame = a > 1e-12f && a < 1e12f && h.t == h.t &&
                       __builtin_fabsf(ray.o.x) < big && __builtin_fabsf(ray.o.y) < big && __builtin_fabsf(ray.o.z) < big;
     const bool walking = tracing && tame;
     bool listed = tracing && !tame;   // lanes that take the run in list order
@@ -768,8 +837,8 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
     for (uint32_t k = threadIdx.x; k < 768; k += blockDim.x) lds.sphere[k] = fr.tbl_sphere[k];
     if (threadIdx.x == 0) lds.next_item = 0u;
     if (MODES & 2) {
-        const RT_CONST_AS f4 *src = sc.tree_rec + 10u * (size_t)dsc.lds_first_step;
-        for (uint32_t k = threadIdx.x; k < dsc.lds_steps * 10u; k += blockDim.x) lds.tree_top[k] = src[k];
+        const RT_CONST_AS f4 *src = sc.tree_rec + (size_t)dsc.lds_first;
+        for (uint32_t k = threadIdx.x; k < dsc.lds_count; k += blockDim.x) lds.tree_top[k] = src[k];
     }
     __syncthreads();
 

@@ -8,8 +8,8 @@
 //   RUN_FLAT   (spheres) list order, but eight spheres per step first go through
 //              a conservative rejection test on packed FMAs;
 //   RUN_TREE   (spheres, triangles) the run is re-ordered by recursive median
-//              splits and an implicit 8-ary tree of bounding spheres is laid over it; the same
-//              rejection test prunes whole subtrees.  Ties between equal hit
+//              splits and an implicit 8-ary tree is laid over it (bounding boxes above,
+//              the rejection test on the primitives' own balls at the leaves).  Ties between equal hit
 //              distances are resolved by list position explicitly, so the result
 //              equals the list-order scan.
 #include "rt_scene_build.h"
@@ -23,6 +23,7 @@
 namespace {
 
 inline float bits_to_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+inline uint32_t float_to_bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 
 struct Ball { double x, y, z, r; };
 
@@ -156,100 +157,87 @@ void append_tree_step(std::vector<float4> &out, const float4 *recs, const float 
     out.push_back(make_float4(radii[4], radii[5], radii[6], radii[7]));
 }
 
-// Builds the levels of the implicit 8-ary tree over `leaves` (already in sorted
-// order) and appends their records to scene.cull_rec.  leaf_eps is the margin of
-// level 0; rho[k] is the radius that scales the guard band of leaf k (its own
-// radius).  Level L >= 1 holds one ball per 8-record step of level L-1; a ball's
-// margin is leaf_eps * 2^j with 2^j >= 2 * (its radius / the smallest rho below
-// it): a ray that clears the ball by that margin clears every leaf below it by
-// the leaf's own margin (a near miss of the ball at a point where a small leaf
-// touches it from inside is the binding case).  That scaling is what spheres
-// need, because the f32 discriminant of Sphere::hit is uncertain by an amount
-// that does not shrink with the sphere (about 20 ulp of |o-c|^2); it is capped
-// at 2^-7, which is enough for any ratio.  A triangle hit is gated by its ball
-// (tri_gate), so the only uncertainty is that of the hit point o + t*d, a
-// DISTANCE of a few ulp of |o| + |o-g| whatever the triangle's size: a ray that
-// clears a ball (C, R) with D^2 - R^2 > eps (|o|^2 + |C|^2 + R^2) passes it at
-// more than eps (|o| + |C| + R) / 3, which one constant margin covers at every
-// level (scale_with_ratio = false).
-void build_tree(HostScene &sc, DevRun &run, const std::vector<Ball> &leaves, double leaf_eps,
-                bool scale_with_ratio) {
-    struct Node { Ball b; double rho_min; };
-    std::vector<Node> cur(leaves.size());
+// smallest float >= v is round_up; largest float <= v:
+float round_down(double v) {
+    float f = (float)v;
+    if ((double)f > v) f = std::nextafterf(f, -INFINITY);
+    return f;
+}
+
+// Builds the implicit 8-ary tree over `leaves` (bounding balls of the primitives, already in
+// slot order) and appends its records to scene.tree_rec.
+//   level 0   the leaves' own rejection records (ten float4 per step of eight), margin
+//             leaf_eps: a ball is a tight fit for a sphere and for a triangle's gate ball;
+//   level L>0 one axis-aligned box per step of level L-1 (twelve float4 per step of eight
+//             boxes: per pair of boxes {lo0,lo1,hi0,hi1} for x, for y, for z).  Boxes hold
+//             the plain extents, rounded outwards; the kernel widens them per ray by a pad
+//             that covers what the reference's f32 arithmetic can add to a primitive's
+//             reach (for a sphere: the root of a discriminant that is uncertain by
+//             kappa |o-c|^2 lies up to sqrt(r^2 + kappa |o-c|^2) from the centre) plus the
+//             rounding of the slab test itself.
+// Boxes fit flat or elongated groups (spheres resting on a plane, a terrain mesh) far better
+// than balls do.  A leaf that is unbounded makes every box above it infinite.
+void build_tree(HostScene &sc, DevRun &run, const std::vector<Ball> &leaves, double leaf_eps) {
+    struct Box { double lo[3], hi[3]; };
     double rho_all = INFINITY;
+    std::vector<Box> cur(leaves.size());
+    std::vector<float4> recs;
+    std::vector<float> radii;
     for (size_t k = 0; k < leaves.size(); ++k) {
-        cur[k] = {leaves[k], std::abs(leaves[k].r)};
-        if (!unbounded(leaves[k])) rho_all = std::min(rho_all, std::abs(leaves[k].r));
+        const Ball &b = leaves[k];
+        float4 rec = reject_record(b, leaf_eps);
+        if (rec.w == 0.0f) rec.w = 0.0f;   // no negative zero: the kernel reads sign bits
+        recs.push_back(rec);
+        radii.push_back(round_up(std::abs(b.r) * (1.0 + 1e-6)));
+        const double r = std::abs(b.r);
+        if (unbounded(b)) {
+            cur[k] = {{-INFINITY, -INFINITY, -INFINITY}, {INFINITY, INFINITY, INFINITY}};
+        } else {
+            cur[k] = {{b.x - r, b.y - r, b.z - r}, {b.x + r, b.y + r, b.z + r}};
+            rho_all = std::min(rho_all, r);
+            run.reach = std::max(run.reach, round_up(std::sqrt(b.x * b.x + b.y * b.y + b.z * b.z) + r));
+        }
     }
     run.inv_2rho = rho_all > 0 && rho_all < INFINITY ? round_up(0.5 / rho_all) : INFINITY;
-    uint32_t level = 0;
-    double eps = leaf_eps;
-    for (;;) {
-        // emit this level, padded to whole steps of 8 records
-        std::vector<float4> recs;
-        std::vector<float> radii;
-        recs.reserve((cur.size() + 7) / 8 * 8);
-        for (const Node &n : cur) {
-            float4 rec = reject_record(n.b, eps);
-            if (rec.w == 0.0f) rec.w = 0.0f;   // no negative zero: the kernel reads sign bits
-            recs.push_back(rec);
-            radii.push_back(round_up(std::abs(n.b.r) * (1.0 + 1e-6)));
-            const double reach = std::sqrt(n.b.x * n.b.x + n.b.y * n.b.y + n.b.z * n.b.z) + std::abs(n.b.r);
-            if (!unbounded(n.b)) run.reach = std::max(run.reach, round_up(reach));
+    while (recs.size() % 8) { recs.push_back(NEVER_PASS); radii.push_back(0.0f); }
+    run.level_base[0] = (uint32_t)sc.tree_rec.size();
+    run.level_aux[0] = float_to_bits((float)(1.0 - leaf_eps));
+    for (size_t k = 0; k < recs.size(); k += 8) append_tree_step(sc.tree_rec, &recs[k], &radii[k]);
+
+    for (uint32_t level = 1;; ++level) {
+        // one box per step (eight records) of the level below
+        const size_t m = (cur.size() + 7) / 8;
+        std::vector<Box> up(m);
+        for (size_t k = 0; k < m; ++k) {
+            Box bx = {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
+            for (size_t c = 8 * k; c < std::min(cur.size(), 8 * k + 8); ++c)
+                for (int ax = 0; ax < 3; ++ax) {
+                    bx.lo[ax] = std::min(bx.lo[ax], cur[c].lo[ax]);
+                    bx.hi[ax] = std::max(bx.hi[ax], cur[c].hi[ax]);
+                }
+            up[k] = bx;
         }
-        while (recs.size() % 8) { recs.push_back(NEVER_PASS); radii.push_back(0.0f); }
-        run.level_base[level] = (uint32_t)(sc.tree_rec.size() / 10);   // in steps (10 float4 each)
-        run.level_keep[level] = (float)(1.0 - eps);
-        for (size_t k = 0; k < recs.size(); k += 8) append_tree_step(sc.tree_rec, &recs[k], &radii[k]);
-        const size_t n_steps = recs.size() / 8;
+        run.level_base[level] = (uint32_t)sc.tree_rec.size();
+        run.level_aux[level] = (uint32_t)m;
+        const size_t n_steps = (m + 7) / 8;
+        for (size_t st = 0; st < n_steps; ++st) {
+            float lo[8][3], hi[8][3];
+            for (size_t c = 0; c < 8; ++c)
+                for (int ax = 0; ax < 3; ++ax) {
+                    const bool have = 8 * st + c < m;   // children past the end are masked out by the kernel
+                    lo[c][ax] = have ? round_down(up[8 * st + c].lo[ax]) : INFINITY;
+                    hi[c][ax] = have ? round_up(up[8 * st + c].hi[ax]) : -INFINITY;
+                }
+            for (int pr = 0; pr < 4; ++pr)
+                for (int ax = 0; ax < 3; ++ax)
+                    sc.tree_rec.push_back(make_float4(lo[2 * pr][ax], lo[2 * pr + 1][ax], hi[2 * pr][ax], hi[2 * pr + 1][ax]));
+        }
         if (n_steps == 1 || level + 1 == DEV_MAX_LEVELS) {
             run.n_levels = level + 1;
             run.top_steps = (uint32_t)n_steps;
             return;
         }
-        // next level: one ball around each step
-        std::vector<Node> up(n_steps);
-        double max_ratio = 1.0;
-        for (size_t s = 0; s < n_steps; ++s) {
-            const size_t b0 = s * 8, b1 = std::min(cur.size(), b0 + 8);
-            double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-            double rho_min = INFINITY;
-            bool open = false;
-            for (size_t k = b0; k < b1; ++k) {
-                const Ball &c = cur[k].b;
-                if (unbounded(c)) { open = true; continue; }
-                const double p[3] = {c.x, c.y, c.z};
-                const double r = std::abs(c.r);
-                for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[a] - r); hi[a] = std::max(hi[a], p[a] + r); }
-                rho_min = std::min(rho_min, cur[k].rho_min);
-            }
-            if (open) { up[s] = {UNBOUNDED, rho_min}; continue; }
-            Ball m{(lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, (lo[2] + hi[2]) / 2, 0.0};
-            // the float centre the kernel sees is what distances are measured from
-            m.x = (float)m.x; m.y = (float)m.y; m.z = (float)m.z;
-            for (size_t k = b0; k < b1; ++k) {
-                const Ball &c = cur[k].b;
-                const double d = std::sqrt((c.x - m.x) * (c.x - m.x) + (c.y - m.y) * (c.y - m.y) + (c.z - m.z) * (c.z - m.z));
-                m.r = std::max(m.r, d + std::abs(c.r));
-            }
-            m.r *= 1.0 + 1e-6;
-            m = bounded_or_unbounded(m);
-            up[s] = {m, rho_min};
-            if (unbounded(m)) continue;
-            max_ratio = std::max(max_ratio, rho_min > 0 ? m.r / rho_min : INFINITY);
-        }
-        if (scale_with_ratio) {
-            // 2^-7 is enough whatever the ratio: a ray that clears a ball (C, R) by
-            // D^2 - R^2 > eps S (S = |o|^2 + |C|^2 + R^2) passes every point of it at
-            // D - R > eps S / (D + R) >= eps sqrt(S/3), and a sphere of any radius inside
-            // the ball is missed by Sphere::hit once the gap exceeds sqrt(kappa) |o-c| <=
-            // sqrt(3 kappa S), kappa = 19.5 ulp: eps >= 3 sqrt(kappa) = 3.3e-3 suffices.
-            int j = 1;
-            while (std::ldexp(1.0, j) < 2.0 * max_ratio && j < 40) ++j;
-            eps = std::min(leaf_eps * std::ldexp(1.0, j), 1.0 / 128.0);
-        }
         cur.swap(up);
-        ++level;
     }
 }
 
@@ -333,13 +321,13 @@ int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::strin
                 sc.order[run.order_base + order[k]] = k;   // list position within the run -> slot offset
             }
             if (run.mode == RUN_TREE) {
-                build_tree(sc, run, sorted, LEAF_EPS_SPHERE, true);
+                build_tree(sc, run, sorted, LEAF_EPS_SPHERE);
             } else if (run.mode == RUN_FLAT) {
                 std::vector<float4> recs;
                 for (const Ball &b : sorted) recs.push_back(reject_record(b, LEAF_EPS_SPHERE));
                 while (recs.size() % 16) recs.push_back(NEVER_PASS);   // two steps per loop trip
                 run.level_base[0] = (uint32_t)(sc.cull_rec.size() / 8);
-                run.level_keep[0] = (float)(1.0 - LEAF_EPS_SPHERE);
+                run.level_aux[0] = float_to_bits((float)(1.0 - LEAF_EPS_SPHERE));
                 run.n_levels = 1;
                 run.top_steps = (uint32_t)(recs.size() / 8);
                 append_paired(sc.cull_rec, recs);
@@ -400,14 +388,14 @@ int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::strin
                 sc.tri_id.push_back(id + order[k]);
                 sc.order[run.order_base + order[k]] = k;
             }
-            if (run.mode == RUN_TREE) build_tree(sc, run, sorted, LEAF_EPS_TRI, false);
+            if (run.mode == RUN_TREE) build_tree(sc, run, sorted, LEAF_EPS_TRI);
         }
         sc.runs.push_back(run);
         id = end;
     }
     // Which tree keeps its top levels in LDS: the largest one; as many levels from
     // the top as fit.  A tree's levels are laid out bottom-up, so levels >= L are the
-    // contiguous tail [level_base[L], level_base[top] + top_steps).
+    // contiguous tail [level_base[L], end of the top level).
     uint32_t best = 0;
     for (uint32_t r = 0; r < sc.runs.size(); ++r) {
         const DevRun &run = sc.runs[r];
@@ -417,13 +405,13 @@ int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::strin
         if (run.count <= best) continue;
         best = run.count;
         const uint32_t top = run.n_levels - 1u;
-        const uint32_t end_step = run.level_base[top] + run.top_steps;
+        const uint32_t end = run.level_base[top] + run.top_steps * 12u;   // top >= 1: a box level
         uint32_t L = top;
-        while (L > 0 && end_step - run.level_base[L - 1] <= DEV_TREE_LDS_STEPS) --L;
-        if (end_step - run.level_base[L] > DEV_TREE_LDS_STEPS) continue;   // even the top level alone is too big
+        while (L > 0 && end - run.level_base[L - 1] <= DEV_TREE_LDS_F4) --L;
+        if (end - run.level_base[L] > DEV_TREE_LDS_F4) continue;   // even the top level alone is too big
         sc.lds_run = r; sc.lds_level = L;
-        sc.lds_first_step = run.level_base[L];
-        sc.lds_steps = end_step - run.level_base[L];
+        sc.lds_first = run.level_base[L];
+        sc.lds_count = end - run.level_base[L];
     }
     return RT_OK;
 }

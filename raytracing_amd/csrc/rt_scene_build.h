@@ -19,7 +19,7 @@ struct HostScene {
     std::vector<float4> mat_albedo;
     std::vector<int32_t> mat_kind;
     uint32_t need_ff_shared = 0;
-    uint32_t lds_run = 0xffffffffu, lds_level = 0, lds_first_step = 0, lds_steps = 0;
+    uint32_t lds_run = 0xffffffffu, lds_level = 0, lds_first = 0, lds_count = 0;
     uint32_t modes = 0;
 };
 
