@@ -90,10 +90,11 @@ typedef struct rt_scene {
      * two-sided Moller-Trumbore with e1 = v1-v0, e2 = v2-v0, plain f32
      * mul/add, miss when det == 0, u < 0, u > 1, v < 0, u+v > 1,
      * t < t_min or t_max < t.  A hit then counts only if the hit point
-     * p = o + t*d lies in the triangle's bounding ball, |p - g|^2 <= R2 with
-     * g = v0 + (e1 + e2) * (1/3) and R2 = 1.0078125 * max |vertex - g|^2 +
-     * 2^-30 |g|^2: evaluated in f32, the barycentric test alone accepts points
-     * far outside a sliver or a triangle seen edge-on, and may yield NaN.
+     * p = o + t*d lies in the bounding box of v0, v0+e1, v0+e2 widened on
+     * every side by 2^-7 of its largest extent plus 2^-20 of the largest
+     * |coordinate| among the vertices and o: evaluated in f32, the
+     * barycentric test alone accepts points far outside a sliver or a
+     * triangle seen edge-on, and may yield NaN (NaN fails the box test).
      * Outward normal unit(cross(e1, e2)), then set_face_normal and the material
      * scatter like a Sphere. */
     uint32_t n_tris;

@@ -29,7 +29,7 @@
  * schedule the GPU library implements (rt_hip.h, RT_SAMPLING_DET).
  *
  * Triangles have no counterpart in the reference sources; tri_hit() is the
- * definition given in rt_hip.h (Moller-Trumbore plus the bounding-ball gate).
+ * definition given in rt_hip.h (Moller-Trumbore plus the bounding-box gate).
  */
 #include <math.h>
 #include <pthread.h>
@@ -119,22 +119,24 @@ static inline void set_face_normal(hit_record *hr, const ray_t *ray, vec3 outwar
 /* --------------------------------------------------------- scene storage */
 typedef struct { int32_t kind; vec3 albedo; float param; } material_t;
 
-/* Gate of the triangle test (rt_hip.h): a hit counts only if the hit point lies in
- * the ball around g = v0 + (e1 + e2)/3 whose squared radius is
- * 1.0078125 * max |vertex - g|^2 + 2^-30 |g|^2, all in binary32, left to right. */
-static vec3 tri_gate_centre(vec3 v0, vec3 e1, vec3 e2) {
-    return v_add(v0, v_mulf(v_add(e1, e2), 0.33333334f));
+/* Gate of the triangle test (rt_hip.h): a hit counts only if the hit point p lies in the
+ * triangle's bounding box widened by
+ *   delta = 2^-7 * (largest extent of the box) + 2^-20 * (largest |coordinate| of the
+ *           three vertices and of the ray origin),
+ * the vertices being v0, v0 + e1, v0 + e2; all in binary32, in the order written here. */
+static float max3f(float a, float b, float c) { float m = a > b ? a : b; return m > c ? m : c; }
+static float min3f(float a, float b, float c) { float m = a < b ? a : b; return m < c ? m : c; }
+static int tri_gate(vec3 v0, vec3 e1, vec3 e2, vec3 o, vec3 p) {
+    vec3 v1 = v_add(v0, e1), v2 = v_add(v0, e2);
+    vec3 lo = v3(min3f(v0.x, v1.x, v2.x), min3f(v0.y, v1.y, v2.y), min3f(v0.z, v1.z, v2.z));
+    vec3 hi = v3(max3f(v0.x, v1.x, v2.x), max3f(v0.y, v1.y, v2.y), max3f(v0.z, v1.z, v2.z));
+    float ext = max3f(hi.x - lo.x, hi.y - lo.y, hi.z - lo.z);
+    float mag = max3f(max3f(fabsf(lo.x), fabsf(lo.y), fabsf(lo.z)), max3f(fabsf(hi.x), fabsf(hi.y), fabsf(hi.z)),
+                      max3f(fabsf(o.x), fabsf(o.y), fabsf(o.z)));
+    float delta = ext * 0.0078125f + mag * 9.5367431640625e-07f;
+    return p.x >= lo.x - delta && p.x <= hi.x + delta && p.y >= lo.y - delta && p.y <= hi.y + delta &&
+           p.z >= lo.z - delta && p.z <= hi.z + delta;   /* any NaN: no hit */
 }
-static float tri_gate_r2(vec3 v0, vec3 e1, vec3 e2) {
-    vec3 g = tri_gate_centre(v0, e1, e2);
-    vec3 w0 = v_sub(v0, g), w1 = v_sub(v_add(v0, e1), g), w2 = v_sub(v_add(v0, e2), g);
-    float m = v_dot(w0, w0), m1 = v_dot(w1, w1), m2 = v_dot(w2, w2);
-    if (m1 > m) m = m1;
-    if (m2 > m) m = m2;
-    return m * 1.0078125f + v_dot(g, g) * 9.313225746154785e-10f;
-}
-
-
 
 enum { K_SPHERE = 0, K_PLANE = 1, K_CUBE = 2, K_TRI = 3 };
 
@@ -144,7 +146,7 @@ typedef struct {
     /* sphere: a = center, f0 = radius
      * plane:  a = normal, b = point
      * cube:   a = center, f0,f1,f2 = w,h,d, b = corner0, c = corner1
-     * tri:    a = v0, b = e1, c = e2, f0 = squared gate radius */
+     * tri:    a = v0, b = e1, c = e2 */
     vec3 a, b, c;
     float f0, f1, f2;
 } prim_t;
@@ -209,7 +211,6 @@ static int scene_build(const rt_scene *in, scene_t *out) {
         vec3 v1 = v3(in->tri_v1x[k], in->tri_v1y[k], in->tri_v1z[k]);
         vec3 v2 = v3(in->tri_v2x[k], in->tri_v2y[k], in->tri_v2z[k]);
         p->a = v0; p->b = v_sub(v1, v0); p->c = v_sub(v2, v0);
-        p->f0 = tri_gate_r2(p->a, p->b, p->c);
     }
 #undef PLACE
     free(seen);
@@ -449,8 +450,7 @@ static int tri_hit(const scene_t *sc, const prim_t *tr, const ray_t *ray, vec3 *
     if (v < 0.0f || u + v > 1.0f) return 0;
     float t = f * v_dot(tr->c, q);
     if (t < t_min || t_max < t) return 0;
-    vec3 w = v_sub(ray_at(ray, t), tri_gate_centre(tr->a, tr->b, tr->c));
-    if (!(v_dot(w, w) <= tr->f0)) return 0;
+    if (!tri_gate(tr->a, tr->b, tr->c, ray->origin, ray_at(ray, t))) return 0;
     hr->t = t;
     hr->p = ray_at(ray, t);
     vec3 outward = v_unit(v_cross(tr->b, tr->c));

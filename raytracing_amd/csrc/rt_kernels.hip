@@ -248,8 +248,12 @@ __device__ __forceinline__ void sphere_exact(const SceneView &sc, uint32_t slot,
         ff_shared = dot(ray.d, outward) < 0.0f;
     }
 }
+// same selections as `m = a > b ? a : b; m > c ? m : c` (and < for min): with a NaN operand the
+// results may differ from a fused max3, so they are spelled out
+__device__ __forceinline__ float max3(float a, float b, float c) { float m = a > b ? a : b; return m > c ? m : c; }
+__device__ __forceinline__ float min3(float a, float b, float c) { float m = a < b ? a : b; return m < c ? m : c; }
 // Triangle (defined by rt_hip.h, absent from the reference): Moller-Trumbore, then the
-// bounding-ball gate that keeps the f32 barycentric test from accepting points far outside
+// bounding-box gate that keeps the f32 barycentric test from accepting points far outside
 // a sliver or an edge-on triangle
 __device__ __forceinline__ void tri_exact(const SceneView &sc, uint32_t slot, int32_t id, const Ray &ray,
                                           float t_min, Hit &h, bool &ff_shared) {
@@ -269,9 +273,19 @@ __device__ __forceinline__ void tri_exact(const SceneView &sc, uint32_t slot, in
     if (v < 0.0f || u + v > 1.0f) return;
     float t = f * dot(E2, q);
     if (t < t_min || h.t < t) return;
-    // gate: the hit point must lie in the ball around g = v0 + (e1 + e2)/3 (e1.w = radius^2)
-    V3 w = (ray.o + ray.d * t) - (mk(v0.x, v0.y, v0.z) + (E1 + E2) * 0.33333334f);
-    if (!(len2(w) <= e1.w)) return;
+    // gate: the hit point must lie in the widened bounding box of the triangle
+    {
+        const V3 a0 = mk(v0.x, v0.y, v0.z), a1 = a0 + E1, a2 = a0 + E2, p = ray.o + ray.d * t;
+        const V3 lo = mk(min3(a0.x, a1.x, a2.x), min3(a0.y, a1.y, a2.y), min3(a0.z, a1.z, a2.z));
+        const V3 hi = mk(max3(a0.x, a1.x, a2.x), max3(a0.y, a1.y, a2.y), max3(a0.z, a1.z, a2.z));
+        const float ext = max3(hi.x - lo.x, hi.y - lo.y, hi.z - lo.z);
+        const float mag = max3(max3(__builtin_fabsf(lo.x), __builtin_fabsf(lo.y), __builtin_fabsf(lo.z)),
+                               max3(__builtin_fabsf(hi.x), __builtin_fabsf(hi.y), __builtin_fabsf(hi.z)),
+                               max3(__builtin_fabsf(ray.o.x), __builtin_fabsf(ray.o.y), __builtin_fabsf(ray.o.z)));
+        const float delta = ext * 0.0078125f + mag * 9.5367431640625e-07f;
+        if (!(p.x >= lo.x - delta && p.x <= hi.x + delta && p.y >= lo.y - delta && p.y <= hi.y + delta &&
+              p.z >= lo.z - delta && p.z <= hi.z + delta)) return;
+    }
     if (t == h.t && id < h.id) return;
     h.t = t; h.kind = DEV_TRI; h.slot = slot; h.id = id;
     if (sc.need_ff_shared) {
@@ -412,18 +426,19 @@ __device__ __forceinline__ void scan_flat(const SceneView &sc, const RunView &ru
 
 // ----------------------------------------------------------------------
 // RUN_TREE: the run's primitives are stored in a spatially hierarchical order under an
-// implicit 8-ary tree.  Level 0 holds their own ball records in steps of eight, level L+1
-// one bounding box per step of level L (the children of step s of level L+1 are the steps
-// 8s..8s+7 one level down).  Every lane walks the tree for its own ray.  No stack: the path
-// is the step index itself (parent = s >> 3), the children still to visit are one byte per
-// level in a 64-bit register.
+// implicit 8-ary tree.  Level 0 holds the primitives' own records in steps of eight (balls
+// for spheres, gate boxes for triangles), level L+1 one bounding box per step of level L
+// (the children of step s of level L+1 are the steps 8s..8s+7 one level down).  Every lane
+// walks the tree for its own ray.  No stack: the path is the step index itself
+// (parent = s >> 3), the children still to visit are one byte per level in a 64-bit register.
 //
-// The wave alternates between two loops so that each runs one kind of node for all its
-// lanes: the box loop, in which every lane that stands on a box node fetches ITS node
-// (192 bytes), tests the eight child boxes and descends into the nearest survivor, until no
-// lane stands on a box node; then one leaf step, in which every lane that has reached a
-// leaf step tests its eight balls, runs the exact test on the survivors, and moves on to its
-// next pending node.  The walk ends when a ballot says no lane has a node left.
+// Box step: a lane fetches ITS node (192 bytes), tests the eight child boxes and descends
+// into the survivor the ray enters first; on the triangles' leaf level the survivors get the
+// exact test instead.  Ball step (spheres' leaf level): the eight balls of the step go
+// through the rejection test, survivors get the exact test.  A wave of a sphere tree has
+// lanes of both kinds; each trip it runs the kind more of its lanes wait for, the others sit
+// the trip out.  After a leaf step, or when no child survives, a lane moves on to its next
+// pending node; the walk ends when a ballot says no lane has a node left.
 //
 // A child box [lo, hi] is skipped when the ray misses the box widened by `pad` on every
 // side, lies behind the origin, or starts beyond closest_so_far (slab test:
@@ -434,10 +449,11 @@ __device__ __forceinline__ void scan_flat(const SceneView &sc, const RunView &ru
 //   (a) spheres: the discriminant of Sphere::hit is uncertain by kappa a |o-c|^2 with
 //       kappa < 2^-19, so a root lies up to sqrt(r^2 + kappa |o-c|^2) from the centre:
 //       at most min(sqrt(kappa) S, kappa S^2 / (2 r_min)) beyond r;
-//       triangles: the gate ball is exact, the hit point o + t*d is off by < 4 ulp S;
+//       triangles: the gate box grows by 2^-20 |o|, the hit point o + t*d it is applied
+//       to is off by < 4 ulp S;
 //   (b) each t is off by a few ulp of (|plane| + |o| + pad) |1/d|, i.e. the plane by a few
-//       ulp of S: 2^-18 S covers (b) and the triangles' (a).
-// A ball of the leaf level is skipped when
+//       ulp of S.  2^-17 S covers (b) and the triangles' (a) three times over.
+// A ball of the spheres' leaf level is skipped when
 //   |o|^2 keep - 2 o.c - max((c-o).u, 0)^2 > thr          (misses sideways / lies behind)
 //   (c-o).u - R > closest_so_far * |d| + slack             (lies beyond the best hit)
 // A lane leaves the walk as soon as its closest_so_far turns NaN (see scan_tree).
@@ -449,17 +465,14 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
     // per-level constants where a lane can index them by its own level
 #pragma unroll
     for (uint32_t L = 0; L < DEV_MAX_LEVELS; ++L) { tbl.base[L] = run.lo[8 + L]; tbl.count[L] = run.hi[L]; }
-    const float len = __builtin_sqrtf(a);
-    const float S = __builtin_sqrtf(cull.oo) + __uint_as_float(run.hi[8]);
+    const float S = __builtin_sqrtf(len2(ray.o)) + __uint_as_float(run.hi[8]);
     float reach_pad = 0.0f;
     if (KIND == DEV_SPHERE) {
         const float kS = S * (1.0f / 524288.0f);
         reach_pad = __builtin_fminf(S * 1.3811e-3f, kS * S * __uint_as_float(run.hi[9]));
     }
-    const float far_pad = S * (1.0f / 1048576.0f) + reach_pad;        // leaf level, a length
-    const float far_len = len * (1.0f + 1.0f / 1048576.0f);
-    const float pad = S * (1.0f / 262144.0f) + reach_pad;             // box levels
-    // slab test constants: t = plane * inv + k, k = -(o -+ pad) * inv
+    const float pad = S * (1.0f / 131072.0f) + reach_pad;
+    // slab test constants: t = plane * inv + k, k = -(o -+ pad) * inv.
     // 1/d clamped to +-1e19: a zero component would make plane * inv and k infinities of
     // opposite sign.  With |d| in (1e-6, 1e6) (see scan_tree) a component below 1e-19 moves
     // the ray by less than 2e-13 S over any distance that matters, far inside the pad.
@@ -468,7 +481,10 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
     const float iz = __builtin_fminf(__builtin_fmaxf(1.0f / ray.d.z, -1e19f), 1e19f);
     const float klx = -((ray.o.x + pad) * ix), kly = -((ray.o.y + pad) * iy), klz = -((ray.o.z + pad) * iz);
     const float khx = -((ray.o.x - pad) * ix), khy = -((ray.o.y - pad) * iy), khz = -((ray.o.z - pad) * iz);
-    const float oo_keep = cull.oo * __uint_as_float(run.hi[0]);
+    // spheres' leaf level
+    const float far_pad = S * (1.0f / 1048576.0f) + reach_pad;        // a length
+    const float far_len = __builtin_sqrtf(a) * (1.0f + 1.0f / 1048576.0f);
+    const float oo_keep = (KIND == DEV_SPHERE) ? cull.oo * __uint_as_float(run.hi[0]) : 0.0f;
     const uint32_t top = run.n_levels - 1u;
     const uint32_t base0 = run.lo[8];
     const RT_CONST_AS f4 *nodes = sc.tree_rec;
@@ -490,12 +506,30 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
                 pend &= ~(1ull << (8u * L + k));
             }
         };
-        while (__builtin_amdgcn_ballot_w64(act) != 0ull) {
-            // ---- box nodes
-            while (__builtin_amdgcn_ballot_w64(act && L != 0u) != 0ull) {
+        // exact test of the primitives of leaf step `st` named by `bits`, in slot order
+        auto exact_tests = [&](uint32_t bits) {
+            while (bits != 0u) {
+                const uint32_t k = (uint32_t)__builtin_ctz(bits);
+                bits &= bits - 1u;
+                const uint32_t idx = 8u * st + k;
+                if (idx < run.count) {
+                    RTK_COUNT(sc, 4, 1);
+                    RTK_COUNT_ANY(sc, 7, 1);
+                    const uint32_t slot = run.first + idx;
+                    if (KIND == DEV_SPHERE) sphere_exact(sc, slot, (int32_t)sc.sph_id[slot], ray, a, t_min, h, ff_shared);
+                    else tri_exact(sc, slot, (int32_t)sc.tri_id[slot], ray, t_min, h, ff_shared);
+                }
+            }
+        };
+        for (;;) {
+            const unsigned long long on_box = __builtin_amdgcn_ballot_w64(act && (KIND == DEV_TRI || L != 0u));
+            const unsigned long long on_ball = (KIND == DEV_TRI) ? 0ull : __builtin_amdgcn_ballot_w64(act && L == 0u);
+            if ((on_box | on_ball) == 0ull) break;
+            if (__builtin_popcountll(on_box) >= __builtin_popcountll(on_ball)) {
+                // ---- box step
                 RTK_COUNT(sc, 2, 1);
-                RTK_COUNT(sc, 5, __builtin_popcountll(__builtin_amdgcn_ballot_w64(act && L != 0u)));
-                if (act && L != 0u) {
+                RTK_COUNT(sc, 5, __builtin_popcountll(on_box));
+                if (act && (KIND == DEV_TRI || L != 0u)) {
                     const uint32_t at = tbl.base[L] + 12u * st;
                     f4 nd[12];
                     if (L >= lds_from_level) {
@@ -540,7 +574,10 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
                     // children past the end of the level below do not exist
                     const uint32_t have = min(8u, tbl.count[L] - 8u * st);
                     const uint32_t bits = ~sign_bits & ((1u << have) - 1u);
-                    if (bits != 0u) {
+                    if (KIND == DEV_TRI && L == 0u) {
+                        exact_tests(bits);
+                        next_pending();
+                    } else if (bits != 0u) {
                         // descend into the surviving child the ray enters first (so that a near
                         // hit bounds the rest of the walk early), remember the others
                         uint32_t k = nearest & 7u;
@@ -552,53 +589,40 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
                         next_pending();
                     }
                 }
-            }
-            // ---- one leaf step for every lane that stands on one
-            if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
-            RTK_COUNT(sc, 3, 1);
-            RTK_COUNT(sc, 6, __builtin_popcountll(__builtin_amdgcn_ballot_w64(act)));
-            if (act) {
-                const RT_CONST_AS f4 *src = nodes + (size_t)(base0 + 10u * st);
-                f4 nd[10];
+            } else if (KIND == DEV_SPHERE) {
+                // ---- ball step
+                RTK_COUNT(sc, 3, 1);
+                RTK_COUNT(sc, 6, __builtin_popcountll(on_ball));
+                if (act && L == 0u) {
+                    const RT_CONST_AS f4 *src = nodes + (size_t)(base0 + 10u * st);
+                    f4 nd[10];
 #pragma unroll
-                for (int q = 0; q < 10; ++q) nd[q] = src[q];
-                const float tl = __builtin_fmaf(h.t, far_len, far_pad);   // inf while nothing is hit
-                uint32_t sign_bits = 0u;
+                    for (int q = 0; q < 10; ++q) nd[q] = src[q];
+                    const float tl = __builtin_fmaf(h.t, far_len, far_pad);   // inf while nothing is hit
+                    uint32_t sign_bits = 0u;
 #pragma unroll
-                for (int pr = 0; pr < 4; ++pr) {
-                    const f4 A = nd[pr];          // cx0, cx1, cy0, cy1
-                    const f4 B = nd[4 + pr];      // cz0, cz1, thr0, thr1
-                    const f4 R4 = nd[8 + (pr >> 1)];
-                    const f2 rr = (pr & 1) ? R4.zw : R4.xy;   // radii of the pair
-                    const f2 ux = {cull.ux, cull.ux}, uy = {cull.uy, cull.uy}, uz = {cull.uz, cull.uz};
-                    const f2 nou = {cull.nou, cull.nou}, ax = {cull.ax, cull.ax}, ay = {cull.ay, cull.ay};
-                    const f2 az = {cull.az, cull.az}, oo = {oo_keep, oo_keep}, tl2 = {tl, tl};
-                    const f2 m = __builtin_elementwise_fma(A.xy, ux, __builtin_elementwise_fma(A.zw, uy, __builtin_elementwise_fma(B.xy, uz, nou)));
-                    const f2 w = __builtin_elementwise_fma(A.xy, ax, __builtin_elementwise_fma(A.zw, ay, __builtin_elementwise_fma(B.xy, az, oo)));
-                    f2 mp;
-                    mp.x = __builtin_fmaxf(m.x, 0.0f); mp.y = __builtin_fmaxf(m.y, 0.0f);
-                    const f2 g = __builtin_elementwise_fma(-mp, mp, w);
-                    const f2 n1 = B.zw - g;             // >= 0: the ray passes within reach sideways
-                    const f2 n2 = (tl2 + rr) - m;       // >= 0: the ball starts before the best hit
-                    const float nx = __builtin_fminf(n1.x, n2.x), ny = __builtin_fminf(n1.y, n2.y);
-                    sign_bits |= (__float_as_uint(nx) >> 31) << (2 * pr);
-                    sign_bits |= (__float_as_uint(ny) >> 31) << (2 * pr + 1);
-                }
-                // exact test of the primitives this lane could not reject, in slot order
-                uint32_t bits = ~sign_bits & 0xffu;
-                while (bits != 0u) {
-                    const uint32_t k = (uint32_t)__builtin_ctz(bits);
-                    bits &= bits - 1u;
-                    const uint32_t idx = 8u * st + k;
-                    if (idx < run.count) {
-                        RTK_COUNT(sc, 4, 1);
-                        RTK_COUNT_ANY(sc, 7, 1);
-                        const uint32_t slot = run.first + idx;
-                        if (KIND == DEV_SPHERE) sphere_exact(sc, slot, (int32_t)sc.sph_id[slot], ray, a, t_min, h, ff_shared);
-                        else tri_exact(sc, slot, (int32_t)sc.tri_id[slot], ray, t_min, h, ff_shared);
+                    for (int pr = 0; pr < 4; ++pr) {
+                        const f4 A = nd[pr];          // cx0, cx1, cy0, cy1
+                        const f4 B = nd[4 + pr];      // cz0, cz1, thr0, thr1
+                        const f4 R4 = nd[8 + (pr >> 1)];
+                        const f2 rr = (pr & 1) ? R4.zw : R4.xy;   // radii of the pair
+                        const f2 ux = {cull.ux, cull.ux}, uy = {cull.uy, cull.uy}, uz = {cull.uz, cull.uz};
+                        const f2 nou = {cull.nou, cull.nou}, ax = {cull.ax, cull.ax}, ay = {cull.ay, cull.ay};
+                        const f2 az = {cull.az, cull.az}, oo = {oo_keep, oo_keep}, tl2 = {tl, tl};
+                        const f2 m = __builtin_elementwise_fma(A.xy, ux, __builtin_elementwise_fma(A.zw, uy, __builtin_elementwise_fma(B.xy, uz, nou)));
+                        const f2 w = __builtin_elementwise_fma(A.xy, ax, __builtin_elementwise_fma(A.zw, ay, __builtin_elementwise_fma(B.xy, az, oo)));
+                        f2 mp;
+                        mp.x = __builtin_fmaxf(m.x, 0.0f); mp.y = __builtin_fmaxf(m.y, 0.0f);
+                        const f2 g = __builtin_elementwise_fma(-mp, mp, w);
+                        const f2 n1 = B.zw - g;             // >= 0: the ray passes within reach sideways
+                        const f2 n2 = (tl2 + rr) - m;       // >= 0: the ball starts before the best hit
+                        const float nx = __builtin_fminf(n1.x, n2.x), ny = __builtin_fminf(n1.y, n2.y);
+                        sign_bits |= (__float_as_uint(nx) >> 31) << (2 * pr);
+                        sign_bits |= (__float_as_uint(ny) >> 31) << (2 * pr + 1);
                     }
+                    exact_tests(~sign_bits & 0xffu);
+                    next_pending();
                 }
-                next_pending();
             }
         }
     }
@@ -673,7 +697,8 @@ __device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, f
     for (uint32_t r = 0; r < sc.n_runs; ++r) {
         const RunView run = load_run(sc, r);
         if (MODES != 0 && run.mode != RUN_EXACT) {
-            if (!have_cull) { cull = cull_setup(ray, a); have_cull = true; }
+            // the ball tests (spheres) need the unit direction and |o|^2; triangle trees are all boxes
+            if (!have_cull && run.kind == DEV_SPHERE) { cull = cull_setup(ray, a); have_cull = true; }
             // levels >= from are read from the LDS copy (only the cached run has any)
             const uint32_t from = (r == sc.lds_run) ? sc.lds_level : 0xffffffffu;
             if ((MODES & 1) && run.mode == RUN_FLAT) scan_flat(sc, run, cull, tracing, ray, a, t_min, h, ff_shared);

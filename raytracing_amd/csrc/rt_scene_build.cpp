@@ -34,6 +34,13 @@ float round_up(double v) {
     return f;
 }
 
+// largest float <= v
+float round_down(double v) {
+    float f = (float)v;
+    if ((double)f > v) f = std::nextafterf(f, -INFINITY);
+    return f;
+}
+
 // A ball the kernel's rejection tests cannot speak for: NaN or infinite numbers, or
 // magnitudes at which the tests' intermediates could overflow.  It is stored as centre
 // 0 with an infinite radius (never rejected, nothing non-finite enters the kernel's
@@ -47,25 +54,32 @@ Ball bounded_or_unbounded(const Ball &b) {
     return UNBOUNDED;
 }
 
-// Gate of the triangle test (rt_hip.h): the ball around g = v0 + (e1 + e2)/3 with squared
-// radius 1.0078125 * max |vertex - g|^2 + 2^-30 |g|^2, every step in binary32, left to
-// right, from the f32 edges the kernel uses.
-struct TriGate { float cx, cy, cz, r2; };
-TriGate tri_gate(const rt_scene *s, uint32_t k) {
-    const float ax = s->tri_v0x[k], ay = s->tri_v0y[k], az = s->tri_v0z[k];
-    const float e1x = s->tri_v1x[k] - ax, e1y = s->tri_v1y[k] - ay, e1z = s->tri_v1z[k] - az;
-    const float e2x = s->tri_v2x[k] - ax, e2y = s->tri_v2y[k] - ay, e2z = s->tri_v2z[k] - az;
-    const float third = 0.33333334f;
-    const float gx = ax + (e1x + e2x) * third, gy = ay + (e1y + e2y) * third, gz = az + (e1z + e2z) * third;
-    auto d2 = [&](float px, float py, float pz) {
-        const float wx = px - gx, wy = py - gy, wz = pz - gz;
-        return wx * wx + wy * wy + wz * wz;
-    };
-    float m = d2(ax, ay, az);
-    const float m1 = d2(ax + e1x, ay + e1y, az + e1z), m2 = d2(ax + e2x, ay + e2y, az + e2z);
-    if (m1 > m) m = m1;
-    if (m2 > m) m = m2;
-    return {gx, gy, gz, m * 1.0078125f + (gx * gx + gy * gy + gz * gz) * 9.313225746154785e-10f};
+// Bounding box of a leaf or node, in double; (-inf, +inf) when unbounded.
+struct Box { double lo[3], hi[3]; };
+const Box EVERYWHERE = {{-INFINITY, -INFINITY, -INFINITY}, {INFINITY, INFINITY, INFINITY}};
+
+// Gate of the triangle test (rt_hip.h): the bounding box of v0, v0+e1, v0+e2 widened by
+// 2^-7 of its largest extent plus 2^-20 of the largest |coordinate|, every step in
+// binary32 from the f32 edges the kernel uses.  The kernel's gate also counts the ray
+// origin among the coordinates; that part is covered by the pad of the slab test.
+Box tri_gate_box(const rt_scene *s, uint32_t k) {
+    const float v0[3] = {s->tri_v0x[k], s->tri_v0y[k], s->tri_v0z[k]};
+    const float e1[3] = {s->tri_v1x[k] - v0[0], s->tri_v1y[k] - v0[1], s->tri_v1z[k] - v0[2]};
+    const float e2[3] = {s->tri_v2x[k] - v0[0], s->tri_v2y[k] - v0[1], s->tri_v2z[k] - v0[2]};
+    float lo[3], hi[3], ext = 0.0f, mag = 0.0f;
+    for (int ax = 0; ax < 3; ++ax) {
+        const float a = v0[ax], b = v0[ax] + e1[ax], c = v0[ax] + e2[ax];
+        lo[ax] = std::min(a, std::min(b, c));
+        hi[ax] = std::max(a, std::max(b, c));
+        if (!(a == a && b == b && c == c)) return EVERYWHERE;   // NaN vertex
+        ext = std::max(ext, hi[ax] - lo[ax]);
+        mag = std::max(mag, std::max(std::abs(lo[ax]), std::abs(hi[ax])));
+    }
+    if (!(mag < BALL_RANGE)) return EVERYWHERE;
+    const float delta = ext * 0.0078125f + mag * 9.5367431640625e-07f;
+    Box bx;
+    for (int ax = 0; ax < 3; ++ax) { bx.lo[ax] = lo[ax] - delta; bx.hi[ax] = hi[ax] + delta; }
+    return bx;
 }
 
 // Rejection record {cx,cy,cz,thr} of the ball (c, r) at margin eps:
@@ -157,53 +171,69 @@ void append_tree_step(std::vector<float4> &out, const float4 *recs, const float 
     out.push_back(make_float4(radii[4], radii[5], radii[6], radii[7]));
 }
 
-// smallest float >= v is round_up; largest float <= v:
-float round_down(double v) {
-    float f = (float)v;
-    if ((double)f > v) f = std::nextafterf(f, -INFINITY);
-    return f;
+// Appends one level of boxes (one per entry of `boxes`, in steps of eight, twelve float4
+// per step: per pair of boxes {lo0,lo1,hi0,hi1} for x, for y, for z), rounded outwards.
+void append_box_level(std::vector<float4> &out, const std::vector<Box> &boxes) {
+    const size_t m = boxes.size(), n_steps = (m + 7) / 8;
+    for (size_t st = 0; st < n_steps; ++st) {
+        float lo[8][3], hi[8][3];
+        for (size_t c = 0; c < 8; ++c)
+            for (int ax = 0; ax < 3; ++ax) {
+                const bool have = 8 * st + c < m;   // children past the end are masked out by the kernel
+                lo[c][ax] = have ? round_down(boxes[8 * st + c].lo[ax]) : INFINITY;
+                hi[c][ax] = have ? round_up(boxes[8 * st + c].hi[ax]) : -INFINITY;
+            }
+        for (int pr = 0; pr < 4; ++pr)
+            for (int ax = 0; ax < 3; ++ax)
+                out.push_back(make_float4(lo[2 * pr][ax], lo[2 * pr + 1][ax], hi[2 * pr][ax], hi[2 * pr + 1][ax]));
+    }
 }
 
-// Builds the implicit 8-ary tree over `leaves` (bounding balls of the primitives, already in
-// slot order) and appends its records to scene.tree_rec.
-//   level 0   the leaves' own rejection records (ten float4 per step of eight), margin
-//             leaf_eps: a ball is a tight fit for a sphere and for a triangle's gate ball;
-//   level L>0 one axis-aligned box per step of level L-1 (twelve float4 per step of eight
-//             boxes: per pair of boxes {lo0,lo1,hi0,hi1} for x, for y, for z).  Boxes hold
-//             the plain extents, rounded outwards; the kernel widens them per ray by a pad
-//             that covers what the reference's f32 arithmetic can add to a primitive's
-//             reach (for a sphere: the root of a discriminant that is uncertain by
-//             kappa |o-c|^2 lies up to sqrt(r^2 + kappa |o-c|^2) from the centre) plus the
-//             rounding of the slab test itself.
+// Builds the implicit 8-ary tree over the leaves of a run (already in slot order) and
+// appends its records to scene.tree_rec.
+//   level 0   spheres (`balls` given): the spheres' own rejection records, ten float4 per
+//             step of eight, margin leaf_eps - a ball is the tight fit for a sphere;
+//             triangles (`balls` null): their gate boxes, twelve float4 per step of eight;
+//   level L>0 one axis-aligned box per step of level L-1, in steps of eight.
+// Boxes hold plain extents rounded outwards; the kernel widens them per ray by a pad that
+// covers what the reference's f32 arithmetic can add to a primitive's reach (for a sphere:
+// the root of a discriminant that is uncertain by kappa |o-c|^2 lies up to
+// sqrt(r^2 + kappa |o-c|^2) from the centre) plus the rounding of the slab test itself.
 // Boxes fit flat or elongated groups (spheres resting on a plane, a terrain mesh) far better
 // than balls do.  A leaf that is unbounded makes every box above it infinite.
-void build_tree(HostScene &sc, DevRun &run, const std::vector<Ball> &leaves, double leaf_eps) {
-    struct Box { double lo[3], hi[3]; };
-    double rho_all = INFINITY;
-    std::vector<Box> cur(leaves.size());
-    std::vector<float4> recs;
-    std::vector<float> radii;
-    for (size_t k = 0; k < leaves.size(); ++k) {
-        const Ball &b = leaves[k];
-        float4 rec = reject_record(b, leaf_eps);
-        if (rec.w == 0.0f) rec.w = 0.0f;   // no negative zero: the kernel reads sign bits
-        recs.push_back(rec);
-        radii.push_back(round_up(std::abs(b.r) * (1.0 + 1e-6)));
-        const double r = std::abs(b.r);
-        if (unbounded(b)) {
-            cur[k] = {{-INFINITY, -INFINITY, -INFINITY}, {INFINITY, INFINITY, INFINITY}};
-        } else {
-            cur[k] = {{b.x - r, b.y - r, b.z - r}, {b.x + r, b.y + r, b.z + r}};
-            rho_all = std::min(rho_all, r);
-            run.reach = std::max(run.reach, round_up(std::sqrt(b.x * b.x + b.y * b.y + b.z * b.z) + r));
+void build_tree(HostScene &sc, DevRun &run, const std::vector<Ball> *balls, const std::vector<Box> &leaf_boxes,
+                double leaf_eps) {
+    for (const Box &b : leaf_boxes) {
+        if (b.lo[0] == -INFINITY) continue;   // unbounded
+        double far2 = 0.0;
+        for (int ax = 0; ax < 3; ++ax) {
+            const double m = std::max(std::abs(b.lo[ax]), std::abs(b.hi[ax]));
+            far2 += m * m;
         }
+        run.reach = std::max(run.reach, round_up(std::sqrt(far2)));
     }
-    run.inv_2rho = rho_all > 0 && rho_all < INFINITY ? round_up(0.5 / rho_all) : INFINITY;
-    while (recs.size() % 8) { recs.push_back(NEVER_PASS); radii.push_back(0.0f); }
     run.level_base[0] = (uint32_t)sc.tree_rec.size();
-    run.level_aux[0] = float_to_bits((float)(1.0 - leaf_eps));
-    for (size_t k = 0; k < recs.size(); k += 8) append_tree_step(sc.tree_rec, &recs[k], &radii[k]);
+    if (balls) {
+        double rho_all = INFINITY;
+        std::vector<float4> recs;
+        std::vector<float> radii;
+        for (const Ball &b : *balls) {
+            float4 rec = reject_record(b, leaf_eps);
+            if (rec.w == 0.0f) rec.w = 0.0f;   // no negative zero: the kernel reads sign bits
+            recs.push_back(rec);
+            radii.push_back(round_up(std::abs(b.r) * (1.0 + 1e-6)));
+            if (!unbounded(b)) rho_all = std::min(rho_all, std::abs(b.r));
+        }
+        run.inv_2rho = rho_all > 0 && rho_all < INFINITY ? round_up(0.5 / rho_all) : INFINITY;
+        while (recs.size() % 8) { recs.push_back(NEVER_PASS); radii.push_back(0.0f); }
+        run.level_aux[0] = float_to_bits((float)(1.0 - leaf_eps));
+        for (size_t k = 0; k < recs.size(); k += 8) append_tree_step(sc.tree_rec, &recs[k], &radii[k]);
+    } else {
+        run.level_aux[0] = (uint32_t)leaf_boxes.size();
+        append_box_level(sc.tree_rec, leaf_boxes);
+    }
 
+    std::vector<Box> cur = leaf_boxes;
     for (uint32_t level = 1;; ++level) {
         // one box per step (eight records) of the level below
         const size_t m = (cur.size() + 7) / 8;
@@ -219,19 +249,8 @@ void build_tree(HostScene &sc, DevRun &run, const std::vector<Ball> &leaves, dou
         }
         run.level_base[level] = (uint32_t)sc.tree_rec.size();
         run.level_aux[level] = (uint32_t)m;
+        append_box_level(sc.tree_rec, up);
         const size_t n_steps = (m + 7) / 8;
-        for (size_t st = 0; st < n_steps; ++st) {
-            float lo[8][3], hi[8][3];
-            for (size_t c = 0; c < 8; ++c)
-                for (int ax = 0; ax < 3; ++ax) {
-                    const bool have = 8 * st + c < m;   // children past the end are masked out by the kernel
-                    lo[c][ax] = have ? round_down(up[8 * st + c].lo[ax]) : INFINITY;
-                    hi[c][ax] = have ? round_up(up[8 * st + c].hi[ax]) : -INFINITY;
-                }
-            for (int pr = 0; pr < 4; ++pr)
-                for (int ax = 0; ax < 3; ++ax)
-                    sc.tree_rec.push_back(make_float4(lo[2 * pr][ax], lo[2 * pr + 1][ax], hi[2 * pr][ax], hi[2 * pr + 1][ax]));
-        }
         if (n_steps == 1 || level + 1 == DEV_MAX_LEVELS) {
             run.n_levels = level + 1;
             run.top_steps = (uint32_t)n_steps;
@@ -281,7 +300,6 @@ int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::strin
     }
 
     const double LEAF_EPS_SPHERE = 1.0 / 65536.0;   // proven bound of the kernel's test, see cull_pair
-    const double LEAF_EPS_TRI = 1.0 / 65536.0;      // guard band of triangle balls, all levels
 
     for (uint32_t id = 0; id < n;) {
         const int kind = list[id].kind;
@@ -321,7 +339,13 @@ int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::strin
                 sc.order[run.order_base + order[k]] = k;   // list position within the run -> slot offset
             }
             if (run.mode == RUN_TREE) {
-                build_tree(sc, run, sorted, LEAF_EPS_SPHERE);
+                std::vector<Box> boxes(count);
+                for (uint32_t k = 0; k < count; ++k) {
+                    const Ball &b = sorted[k];
+                    const double r = std::abs(b.r);
+                    boxes[k] = unbounded(b) ? EVERYWHERE : Box{{b.x - r, b.y - r, b.z - r}, {b.x + r, b.y + r, b.z + r}};
+                }
+                build_tree(sc, run, &sorted, boxes, LEAF_EPS_SPHERE);
             } else if (run.mode == RUN_FLAT) {
                 std::vector<float4> recs;
                 for (const Ball &b : sorted) recs.push_back(reject_record(b, LEAF_EPS_SPHERE));
@@ -360,35 +384,36 @@ int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::strin
             run.first = (uint32_t)(sc.tris.size() / 3);
             std::vector<uint32_t> order(count);
             std::iota(order.begin(), order.end(), 0u);
-            std::vector<Ball> balls(count);
-            std::vector<float> gate_r2(count);
+            std::vector<Ball> balls(count);    // box centres, for the slot order only
+            std::vector<Box> gate(count);
             for (uint32_t k = 0; k < count; ++k) {
                 const uint32_t src = list[id + k].k;
-                const TriGate g = tri_gate(s, src);
-                gate_r2[k] = g.r2;
-                // every point the gate lets through is within sqrt(r2) of the centre
-                balls[k] = bounded_or_unbounded({g.cx, g.cy, g.cz, std::sqrt((double)g.r2) * (1.0 + 1e-6)});
+                gate[k] = tri_gate_box(s, src);
+                const bool open = gate[k].lo[0] == -INFINITY;
+                balls[k] = open ? UNBOUNDED
+                                : Ball{(gate[k].lo[0] + gate[k].hi[0]) / 2, (gate[k].lo[1] + gate[k].hi[1]) / 2,
+                                       (gate[k].lo[2] + gate[k].hi[2]) / 2, 0.0};
             }
             if (count >= DEV_TREE_MIN_RUN && use_tree) {
                 run.mode = RUN_TREE;
                 order = tree_order(balls);
             }
-            std::vector<Ball> sorted(count);
+            std::vector<Box> sorted(count);
             run.order_base = (uint32_t)sc.order.size();
             sc.order.resize(sc.order.size() + count);
             for (uint32_t k = 0; k < count; ++k) {
                 const uint32_t src = list[id + order[k]].k;
-                sorted[k] = balls[order[k]];
+                sorted[k] = gate[order[k]];
                 const float ax = s->tri_v0x[src], ay = s->tri_v0y[src], az = s->tri_v0z[src];
                 const float e1x = s->tri_v1x[src] - ax, e1y = s->tri_v1y[src] - ay, e1z = s->tri_v1z[src] - az;
                 const float e2x = s->tri_v2x[src] - ax, e2y = s->tri_v2y[src] - ay, e2z = s->tri_v2z[src] - az;
                 sc.tris.push_back(make_float4(ax, ay, az, bits_to_float(s->tri_mat[src])));
-                sc.tris.push_back(make_float4(e1x, e1y, e1z, gate_r2[order[k]]));
+                sc.tris.push_back(make_float4(e1x, e1y, e1z, 0.f));
                 sc.tris.push_back(make_float4(e2x, e2y, e2z, 0.f));
                 sc.tri_id.push_back(id + order[k]);
                 sc.order[run.order_base + order[k]] = k;
             }
-            if (run.mode == RUN_TREE) build_tree(sc, run, sorted, LEAF_EPS_TRI);
+            if (run.mode == RUN_TREE) build_tree(sc, run, nullptr, sorted, 0.0);
         }
         sc.runs.push_back(run);
         id = end;

@@ -292,11 +292,14 @@ def _tri_by_hand(v0, v1, v2, o, d, t_min=f32(0.001)):
     t = f32(f * dot(e2, q))
     if t < t_min:
         return False, False, None
-    g = v0 + (e1 + e2) * f32(0.33333334)
-    m = max(dot(w, w) for w in (v0 - g, (v0 + e1) - g, (v0 + e2) - g))
-    r2 = f32(f32(m * f32(1.0078125)) + f32(dot(g, g) * f32(2.0 ** -30)))
-    w = (o + d * t) - g
-    return True, bool(dot(w, w) <= r2), t
+    a1, a2, p = v0 + e1, v0 + e2, o + d * t
+    lo = np.minimum(np.minimum(v0, a1), a2)
+    hi = np.maximum(np.maximum(v0, a1), a2)
+    ext = (hi - lo).max()
+    mag = max(np.abs(lo).max(), np.abs(hi).max(), np.abs(o).max())
+    delta = f32(f32(ext * f32(2.0 ** -7)) + f32(mag * f32(2.0 ** -20)))
+    inside = bool(np.all(p >= lo - delta) and np.all(p <= hi + delta))
+    return True, inside, t
 
 
 def test_triangle_vertices_and_edges_pass_the_gate(oracle, tables):
