@@ -436,8 +436,8 @@ __device__ __forceinline__ void scan_flat(const SceneView &sc, const RunView &ru
 // into the survivor the ray enters first; on the triangles' leaf level the survivors get the
 // exact test instead.  Ball step (spheres' leaf level): the eight balls of the step go
 // through the rejection test, survivors get the exact test.  A wave of a sphere tree has
-// lanes of both kinds; each trip it runs the kind more of its lanes wait for, the others sit
-// the trip out.  After a leaf step, or when no child survives, a lane moves on to its next
+// lanes of both kinds; each trip it runs one kind (a ball step once half as many lanes wait for
+// one as for a box step), the others sit the trip out.  After a leaf step, or when no child survives, a lane moves on to its next
 // pending node; the walk ends when a ballot says no lane has a node left.
 //
 // A child box [lo, hi] is skipped when the ray misses the box widened by `pad` on every
@@ -525,7 +525,8 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
             const unsigned long long on_box = __builtin_amdgcn_ballot_w64(act && (KIND == DEV_TRI || L != 0u));
             const unsigned long long on_ball = (KIND == DEV_TRI) ? 0ull : __builtin_amdgcn_ballot_w64(act && L == 0u);
             if ((on_box | on_ball) == 0ull) break;
-            if (__builtin_popcountll(on_box) >= __builtin_popcountll(on_ball)) {
+            // a ball step as soon as half as many lanes wait for one as for a box step (measured)
+            if (__builtin_popcountll(on_box) >= 2 * __builtin_popcountll(on_ball)) {
                 // ---- box step
                 RTK_COUNT(sc, 2, 1);
                 RTK_COUNT(sc, 5, __builtin_popcountll(on_box));
