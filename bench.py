@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - throughput of the render loop on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4] [--spp-per-step 16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4] [--spp-per-step 64]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step is one pass of the hot path over the whole frame: `spp-per-step` samples
@@ -9,8 +9,8 @@ of every pixel, added into the per-pixel sums (the progressive form of
 calculate_some_pxls, src/raytracer.rs:232-271), followed by the quantiser and,
 with N > 1 GPUs, one RCCL all-gather of the packed bands.  The default workload
 is the one the headline metric is quoted on: 10,000 random spheres at 3840x2160,
-256 spp; with the defaults (16 steps of 16 spp) the timed region is exactly one
-such frame.  The frame is split over the N ranks by interleaved 8-row bands
+256 spp; with the defaults (8 steps of 64 spp, one kernel launch each) the timed region
+is exactly two such frames.  The frame is split over the N ranks by interleaved 8-row bands
 (strong scaling: the total work is fixed).
 
 Rank 0 prints ONE JSON line.  `value` is Mrays/s over all ranks, a ray being one
@@ -95,6 +95,31 @@ def flat_scan_probe(r, wl, flops_seg):
             "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4),
             "frac_of_no_fma_ceiling": round(achieved / PEAK_FP32_NOFMA_TFLOPS, 4),
             "sample": "8 spp of the full frame, %d segments" % seg}
+
+
+def valu_from_profile(workload, kernel_ms):
+    """VALU instructions per launch of render_tiles from the committed rocprofv3 --pmc pass
+    (profiles/sq_counters.json, tools/collect_sq.py) and what fraction of the SIMDs' issue
+    cycles they fill at the measured cost of 4.2 cycles per wave instruction; None if absent."""
+    path = os.path.join(ROOT, "profiles", "sq_counters.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f).get(workload)
+        insts = rec["per_launch"]["SQ_INSTS_VALU"]
+    except (OSError, ValueError, KeyError, TypeError):
+        return None
+    simd_cycles = 1024 * 2.4e9 * kernel_ms * 1e-3
+    return {"wave_insts_per_launch": int(insts), "spp_per_launch": rec.get("spp_per_launch"),
+            "issue_frac_at_4.2_cycles": round(insts * 4.2 / simd_cycles, 3) if rec.get("spp_per_launch") else None,
+            "source": "profiles/sq_counters.json (rocprofv3 --pmc SQ_INSTS_VALU ...)"}
+
+
+def kernel_variant(flat):
+    """which instantiation of render_tiles the library picks for this scene"""
+    c = flat.counts
+    tree = c["n_spheres"] >= 64 or c["n_tris"] >= 64
+    rej = 32 <= c["n_spheres"] < 64
+    return "render_tiles<%d>" % ((2 if tree else 0) | (1 if rej else 0))
 
 
 def hbm_traffic_from_profile(workload):
@@ -228,13 +253,14 @@ def main():
                 "partition": "interleaved 8-row bands, rank r renders bands r, r+N, ...; "
                              "RCCL all_gather of packed pixels per step" if world > 1 else "single GPU",
                 "sampling": "deterministic schedule (RT_SAMPLING_DET), seed 0",
-                "scan": "bounding-sphere tree over the sphere run (results identical to the list-order scan)",
+                "scan": "implicit 8-ary box tree over each long sphere/triangle run (results identical to the "
+                        "reference's list-order scan)",
             },
             "roofline": {
                 "bound": "valu", "achieved": round(float(achieved), 3), "peak": PEAK_FP32_VECTOR_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(float(achieved) / PEAK_FP32_VECTOR_TFLOPS, 4),
                 "traffic": hbm_traffic_from_profile(args.workload),
-                "kernel": "render_tiles<2>", "kernel_ms": round(float(np.mean(kernel_ms)), 3),
+                "kernel": kernel_variant(wl["flat"]), "kernel_ms": round(float(np.mean(kernel_ms)), 3),
                 "flops_per_segment": flops_seg,
                 "note": "achieved = algorithmic flops of the reference's linear scan (18/sphere + 14/plane + "
                         "18/cube + 45/triangle + 80 per segment, mul/add counted singly) x segments of one launch "
@@ -245,6 +271,9 @@ def main():
         }
         if flat is not None:
             out["roofline"]["flat_scan"] = flat
+        valu = valu_from_profile(args.workload, float(np.mean(kernel_ms)))
+        if valu is not None and valu["spp_per_launch"] == sps:
+            out["roofline"]["valu"] = valu
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, tables)
         print(json.dumps(out), flush=True)

@@ -855,7 +855,10 @@ __device__ __forceinline__ V3 sky(V3 d, bool gamma) {
 // grid.y = number of 8-row bands this call renders.
 // ----------------------------------------------------------------------
 template <int MODES>
-__global__ __launch_bounds__(waves_of(MODES) * 64, 4)   // at most 128 VGPRs: four waves per SIMD
+#ifndef RTK_OCC
+#define RTK_OCC 4
+#endif
+__global__ __launch_bounds__(waves_of(MODES) * 64, RTK_OCC)   // at most 128 VGPRs: four waves per SIMD
 void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
     __shared__ Lds<MODES> lds;
     const SceneView sc = view_of(dsc, fr.segments);
