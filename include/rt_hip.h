@@ -206,6 +206,9 @@ uint32_t rt_image_height(uint32_t width, float aspect_ratio);
 size_t rt_parse_floats(const char *text, size_t len, float *out, size_t cap);
 /* PPM::write_file, src/image/mod.rs:61-67: "P6 {w} {h} 255\n" + RGB bytes */
 int rt_write_ppm(const char *path, const uint32_t *packed, uint32_t width, uint32_t height);
+/* the same pixels as an 8-bit RGB PNG (uncompressed), the format of the reference's
+ * output_images/ - no counterpart in its code, which only blits to a window */
+int rt_write_png(const char *path, const uint32_t *packed, uint32_t width, uint32_t height);
 
 #ifdef __cplusplus
 }

@@ -128,4 +128,5 @@ extern "C" {
     pub fn rt_image_height(width: u32, aspect_ratio: f32) -> u32;
     pub fn rt_parse_floats(text: *const c_char, len: usize, out: *mut f32, cap: usize) -> usize;
     pub fn rt_write_ppm(path: *const c_char, packed: *const u32, width: u32, height: u32) -> c_int;
+    pub fn rt_write_png(path: *const c_char, packed: *const u32, width: u32, height: u32) -> c_int;
 }

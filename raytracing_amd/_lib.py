@@ -97,6 +97,7 @@ SIGNATURES = {
     "rt_image_height": (C.c_uint32, [C.c_uint32, C.c_float]),
     "rt_parse_floats": (C.c_size_t, [C.c_char_p, C.c_size_t, _fp, C.c_size_t]),
     "rt_write_ppm": (C.c_int, [C.c_char_p, _up, C.c_uint32, C.c_uint32]),
+    "rt_write_png": (C.c_int, [C.c_char_p, _up, C.c_uint32, C.c_uint32]),
 }
 
 _lib = None

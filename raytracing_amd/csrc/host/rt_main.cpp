@@ -8,9 +8,9 @@
 //
 //   rt_main [--width 600] [--spp 1] [--frames 10] [--aperture 0] [--bounces 10]
 //           [--no-gamma] [--seed 0] [--device 0] [--data DIR] [--out PREFIX]
-//           [--obj FILE [--obj-scale S] [--obj-at X Y Z]] [--chunk N] [--quiet]
+//           [--obj FILE [--obj-scale S] [--obj-at X Y Z]] [--chunk N] [--quiet] [--png]
 //
-// PREFIX_0000.ppm ... are written when --out is given.  --chunk N renders the
+// PREFIX_0000.ppm ... (.png with --png) are written when --out is given.  --chunk N renders the
 // samples of a frame N at a time (progressive); the picture is the same.
 #include <chrono>
 #include <cstdio>
@@ -28,7 +28,7 @@ struct Options {
     int device = 0;
     float aperture = 0.f, obj_scale = 1.f;
     rt::vec3 obj_at{0.f, 0.f, 0.f};
-    bool gamma = true, quiet = false;
+    bool gamma = true, quiet = false, png = false;
     std::string data = "raytracing_amd/data", out, obj;
 };
 
@@ -36,7 +36,7 @@ struct Options {
     std::fprintf(stderr, "rt_main: %s\n", why);
     std::fprintf(stderr,
                  "usage: rt_main [--width W] [--spp N] [--frames F] [--aperture A] [--bounces B] [--no-gamma]\n"
-                 "               [--seed S] [--device D] [--data DIR] [--out PREFIX] [--chunk N] [--quiet]\n"
+                 "               [--seed S] [--device D] [--data DIR] [--out PREFIX] [--chunk N] [--quiet] [--png]\n"
                  "               [--obj FILE [--obj-scale S] [--obj-at X Y Z]]\n");
     std::exit(2);
 }
@@ -58,6 +58,7 @@ Options parse(int argc, char** argv) {
         else if (a == "--aperture") { need(i, 1); o.aperture = std::strtof(argv[++i], nullptr); }
         else if (a == "--no-gamma") o.gamma = false;
         else if (a == "--quiet") o.quiet = true;
+        else if (a == "--png") o.png = true;
         else if (a == "--data") { need(i, 1); o.data = argv[++i]; }
         else if (a == "--out") { need(i, 1); o.out = argv[++i]; }
         else if (a == "--obj") { need(i, 1); o.obj = argv[++i]; }
@@ -137,9 +138,10 @@ int main(int argc, char** argv) {
             total_ms += ms;
             if (!o.out.empty()) {
                 char name[32];
-                std::snprintf(name, sizeof name, "_%04u.ppm", frame);
+                std::snprintf(name, sizeof name, "_%04u.%s", frame, o.png ? "png" : "ppm");
                 const std::string path = o.out + name;
-                check(ctx, rt_write_ppm(path.c_str(), img_buffer.data(), image_width, image_height), "rt_write_ppm");
+                if (o.png) check(ctx, rt_write_png(path.c_str(), img_buffer.data(), image_width, image_height), "rt_write_png");
+                else check(ctx, rt_write_ppm(path.c_str(), img_buffer.data(), image_width, image_height), "rt_write_ppm");
             }
             if (!o.quiet)
                 std::printf("frame %u: COUNTER %u, %.3f ms, FPS: %.2f, %.1f Mrays/s\n", frame, world.counter, ms,

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "rt_hip.h"
@@ -120,6 +121,81 @@ int rt_write_ppm(const char *path, const uint32_t *packed, uint32_t width, uint3
         }
         ok = std::fwrite(line.data(), 1, line.size(), f) == line.size();
     }
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? RT_OK : RT_E_IO;
+}
+
+// PNG (8-bit RGB, no filtering, stored deflate blocks): the format of the reference's
+// output_images/*.png, for side-by-side viewing.  No compression library is needed.
+namespace {
+uint32_t crc32_update(uint32_t crc, const unsigned char *p, size_t n) {
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        ready = true;
+    }
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+    return crc;
+}
+void put_be32(std::vector<unsigned char> &v, uint32_t x) {
+    v.push_back((unsigned char)(x >> 24)); v.push_back((unsigned char)(x >> 16));
+    v.push_back((unsigned char)(x >> 8)); v.push_back((unsigned char)x);
+}
+bool write_chunk(std::FILE *f, const char type[4], const std::vector<unsigned char> &data) {
+    std::vector<unsigned char> head;
+    put_be32(head, (uint32_t)data.size());
+    head.insert(head.end(), type, type + 4);
+    uint32_t crc = crc32_update(0xffffffffu, head.data() + 4, 4);
+    crc = crc32_update(crc, data.data(), data.size()) ^ 0xffffffffu;
+    std::vector<unsigned char> tail;
+    put_be32(tail, crc);
+    return std::fwrite(head.data(), 1, head.size(), f) == head.size() &&
+           (data.empty() || std::fwrite(data.data(), 1, data.size(), f) == data.size()) &&
+           std::fwrite(tail.data(), 1, 4, f) == 4;
+}
+}  // namespace
+
+int rt_write_png(const char *path, const uint32_t *packed, uint32_t width, uint32_t height) {
+    if (!path || !packed || width == 0 || height == 0) return RT_E_BADARG;
+    // raw image: per row a filter byte 0 then RGB triples
+    std::vector<unsigned char> raw;
+    try { raw.reserve((size_t)height * ((size_t)width * 3 + 1)); } catch (...) { return RT_E_OOM; }
+    for (uint32_t y = 0; y < height; ++y) {
+        raw.push_back(0);
+        for (uint32_t x = 0; x < width; ++x) {
+            const uint32_t c = packed[(size_t)y * width + x];
+            raw.push_back((unsigned char)((c >> 16) & 0xffu));
+            raw.push_back((unsigned char)((c >> 8) & 0xffu));
+            raw.push_back((unsigned char)(c & 0xffu));
+        }
+    }
+    // zlib stream of stored blocks
+    std::vector<unsigned char> z;
+    z.push_back(0x78); z.push_back(0x01);
+    uint32_t a = 1, b = 0;   // adler32
+    for (size_t pos = 0; pos < raw.size();) {
+        const size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + n == raw.size() ? 1 : 0);
+        z.push_back((unsigned char)(n & 0xff)); z.push_back((unsigned char)(n >> 8));
+        z.push_back((unsigned char)(~n & 0xff)); z.push_back((unsigned char)((~n >> 8) & 0xff));
+        z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+        for (size_t k = pos; k < pos + n; ++k) { a = (a + raw[k]) % 65521u; b = (b + a) % 65521u; }
+        pos += n;
+    }
+    put_be32(z, (b << 16) | a);
+    std::FILE *f = std::fopen(path, "wb");
+    if (!f) return RT_E_IO;
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    bool ok = std::fwrite(sig, 1, 8, f) == 8;
+    std::vector<unsigned char> ihdr;
+    put_be32(ihdr, width); put_be32(ihdr, height);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    ok = ok && write_chunk(f, "IHDR", ihdr) && write_chunk(f, "IDAT", z) && write_chunk(f, "IEND", {});
     ok = (std::fclose(f) == 0) && ok;
     return ok ? RT_OK : RT_E_IO;
 }

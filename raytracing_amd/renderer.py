@@ -181,3 +181,13 @@ def write_ppm(path, packed):
     rc = lib.rt_write_ppm(os.fsencode(path), arr.ctypes.data_as(C.POINTER(C.c_uint32)), w, h)
     if rc != 0:
         raise _lib.RtError(rc, "rt_write_ppm(%s)" % path)
+
+
+def write_png(path, packed):
+    """8-bit RGB PNG of the same pixels (the format of the reference's output_images/)"""
+    lib = _lib.load()
+    arr = np.ascontiguousarray(packed, dtype=np.uint32)
+    h, w = arr.shape
+    rc = lib.rt_write_png(os.fsencode(path), arr.ctypes.data_as(C.POINTER(C.c_uint32)), w, h)
+    if rc != 0:
+        raise _lib.RtError(rc, "rt_write_png(%s)" % path)

@@ -166,6 +166,33 @@ def test_ppm_writer(tmp_path):
 
 
 # --------------------------------------------------------------- scene mirror
+def test_png_writer(tmp_path):
+    """signature, IHDR, one zlib stream of stored blocks, CRCs; pixels round-trip"""
+    import struct
+    import zlib
+    from raytracing_amd import write_png
+    rng = np.random.default_rng(5)
+    img = (rng.integers(0, 1 << 24, size=(211, 173))).astype(np.uint32)      # > 65535 raw bytes: several blocks
+    path = tmp_path / "x.png"
+    write_png(str(path), img)
+    raw = path.read_bytes()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(raw):
+        n, typ = struct.unpack(">I4s", raw[pos:pos + 8])
+        data = raw[pos + 8:pos + 8 + n]
+        (crc,) = struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])
+        assert crc == zlib.crc32(typ + data) & 0xffffffff
+        chunks.append((typ, data))
+        pos += 12 + n
+    assert [c[0] for c in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    assert struct.unpack(">IIBBBBB", chunks[0][1]) == (173, 211, 8, 2, 0, 0, 0)
+    pix = np.frombuffer(zlib.decompress(chunks[1][1]), dtype=np.uint8).reshape(211, 173 * 3 + 1)
+    assert (pix[:, 0] == 0).all()
+    rgb = pix[:, 1:].reshape(211, 173, 3).astype(np.uint32)
+    assert np.array_equal((rgb[..., 0] << 16) | (rgb[..., 1] << 8) | rgb[..., 2], img)
+
+
 def test_default_scene_literals():
     """Scene::get_scene src/scene/mod.rs:15-57: order, kinds, materials"""
     flat = Scene.get_scene().flatten()
