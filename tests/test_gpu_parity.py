@@ -106,6 +106,18 @@ def test_progressive_chunks_equal_one_shot(renderer, oracle, tables):
     assert_same(many, render_oracle(oracle, tables, flat, cam, chunks), oracle)
 
 
+def test_sample_ranges_longer_than_one_launch(renderer, oracle, tables):
+    """rt_render cuts a sample range into launches of at most 64 samples; 150 samples in one
+    call, in 70 + 80, and on the oracle are the same sums"""
+    flat = Scene.get_scene().flatten()
+    cam = Scene.get_camera(aperture=0.1)
+    one = render_gpu(renderer, flat, cam, [make_params(40, 24, spp=150)])
+    two = render_gpu(renderer, flat, cam, [make_params(40, 24, spp=150, sample_begin=0, sample_count=70),
+                                           make_params(40, 24, spp=150, sample_begin=70, sample_count=80)])
+    assert np.array_equal(_bits(one[0]), _bits(two[0])) and one[3] == two[3]
+    assert_same(one, render_oracle(oracle, tables, flat, cam, [make_params(40, 24, spp=150)]), oracle)
+
+
 def test_band_partition(renderer, oracle, tables):
     """the multi-GPU split: bands b % 3 == g rendered separately add up to the frame, and
     rt_export_packed_bands lays each share out as the gather expects"""

@@ -37,15 +37,35 @@ def scene(rng):
     if style == 4 and n_t:                              # coplanar sheet: rays graze many at once
         for v in (v0, v1, v2):
             v[:, 1] = off[1]
-    n = n_s + n_t
+    # the list: the spheres and the triangles, each cut into up to three runs by cubes and planes
+    # put at random positions (a cube may be glass: it inherits front_face from the hit before it)
+    n_c, n_p = int(rng.integers(0, 4)), int(rng.integers(0, 3))
+    n = n_s + n_t + n_c + n_p
+    slots = rng.permutation(2) if n_s and n_t else [0, 1]
+    body = []
+    for kind in slots:
+        body += [("s", k) for k in range(n_s)] if kind == 0 else [("t", k) for k in range(n_t)]
+    for k in range(n_c):
+        body.insert(int(rng.integers(0, len(body) + 1)), ("c", k))
+    for k in range(n_p):
+        body.insert(int(rng.integers(0, len(body) + 1)), ("p", k))
+    ids = {"s": np.zeros(n_s, np.uint32), "t": np.zeros(n_t, np.uint32), "c": np.zeros(n_c, np.uint32),
+           "p": np.zeros(n_p, np.uint32)}
+    for pos, (kind, k) in enumerate(body):
+        ids[kind][k] = pos
     kinds = rng.integers(0, 3, n).astype(np.int32)
-    order = rng.permutation(2) if n_s and n_t else [0, 1]
-    sid = np.arange(n_s) + (n_t if order[0] == 1 else 0)
-    tid = np.arange(n_t) + (n_s if order[0] == 0 else 0)
+    cc = (off + rng.uniform(-ext, ext, (n_c, 3))).astype(np.float32)
+    cs = (ext * 10.0 ** rng.uniform(-1.5, 0.3, (n_c, 3))).astype(np.float32)
+    pn = rng.normal(size=(n_p, 3)).astype(np.float32)
+    pp = (off + rng.uniform(-ext, ext, (n_p, 3)) * 1.5).astype(np.float32)
     flat = flat_scene_from_arrays(
-        sph_cx=c[:, 0], sph_cy=c[:, 1], sph_cz=c[:, 2], sph_r=r, sph_mat=sid, sph_id=sid,
+        sph_cx=c[:, 0], sph_cy=c[:, 1], sph_cz=c[:, 2], sph_r=r, sph_mat=ids["s"], sph_id=ids["s"],
         tri_v0x=v0[:, 0], tri_v0y=v0[:, 1], tri_v0z=v0[:, 2], tri_v1x=v1[:, 0], tri_v1y=v1[:, 1], tri_v1z=v1[:, 2],
-        tri_v2x=v2[:, 0], tri_v2y=v2[:, 1], tri_v2z=v2[:, 2], tri_mat=tid, tri_id=tid,
+        tri_v2x=v2[:, 0], tri_v2y=v2[:, 1], tri_v2z=v2[:, 2], tri_mat=ids["t"], tri_id=ids["t"],
+        cb_cx=cc[:, 0], cb_cy=cc[:, 1], cb_cz=cc[:, 2], cb_w=cs[:, 0], cb_h=cs[:, 1], cb_d=cs[:, 2],
+        cb_mat=ids["c"], cb_id=ids["c"],
+        pl_nx=pn[:, 0], pl_ny=pn[:, 1], pl_nz=pn[:, 2], pl_px=pp[:, 0], pl_py=pp[:, 1], pl_pz=pp[:, 2],
+        pl_mat=ids["p"], pl_id=ids["p"],
         mat_kind=kinds, mat_r=rng.uniform(0.2, 1, n), mat_g=rng.uniform(0.2, 1, n), mat_b=rng.uniform(0.2, 1, n),
         mat_param=np.where(kinds == 2, 1.5, rng.uniform(0, 0.4, n)))
     where = rng.integers(0, 3)
