@@ -564,12 +564,14 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
                             tn[c] = enter;
                             nn[c] = leave - enter;   // >= 0: some point of the ray in front of the best hit is inside
                         }
-                        sign_bits |= (__float_as_uint(nn[0]) >> 31) << (2 * pr);
-                        sign_bits |= (__float_as_uint(nn[1]) >> 31) << (2 * pr + 1);
                         // enter >= 0 orders like its bit pattern; the low three bits carry the child
-                        // index, a rejected child becomes all ones
-                        const uint32_t kx = ((__float_as_uint(tn[0]) & ~7u) | (uint32_t)(2 * pr)) | (uint32_t)((int32_t)__float_as_uint(nn[0]) >> 31);
-                        const uint32_t ky = ((__float_as_uint(tn[1]) & ~7u) | (uint32_t)(2 * pr + 1)) | (uint32_t)((int32_t)__float_as_uint(nn[1]) >> 31);
+                        // index, a rejected child (negative nn) becomes all ones
+                        const uint32_t s0 = (uint32_t)((int32_t)__float_as_uint(nn[0]) >> 31);
+                        const uint32_t s1 = (uint32_t)((int32_t)__float_as_uint(nn[1]) >> 31);
+                        sign_bits |= s0 & (1u << (2 * pr));
+                        sign_bits |= s1 & (1u << (2 * pr + 1));
+                        const uint32_t kx = ((__float_as_uint(tn[0]) & ~7u) | (uint32_t)(2 * pr)) | s0;
+                        const uint32_t ky = ((__float_as_uint(tn[1]) & ~7u) | (uint32_t)(2 * pr + 1)) | s1;
                         nearest = min(nearest, min(kx, ky));
                     }
                     // children past the end of the level below do not exist
