@@ -39,7 +39,8 @@ struct Ctx {
     float4 *d_accum = nullptr;
     uint32_t *d_packed = nullptr;
     int32_t *d_ids = nullptr;
-    float4 *d_samples = nullptr;   // DEV_SAMPLE_CHUNK colour planes, see DevFrame::samples
+    float4 *d_samples = nullptr;   // sample_chunk colour planes, see DevFrame::samples
+    uint32_t sample_chunk = 0;     // samples per pixel one launch renders at most
     unsigned long long *d_segments = nullptr;
     bool have_frame = false;
 };
@@ -230,7 +231,10 @@ int rt_begin_frame(rt_ctx *ctx, uint32_t width, uint32_t height) {
         HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_accum), n_px * sizeof(float4)));
         HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_packed), n_px * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_ids), n_px * sizeof(int32_t)));
-        HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_samples), n_px * DEV_SAMPLE_CHUNK * sizeof(float4)));
+        // staging planes for the colours of one launch: up to DEV_SAMPLE_CHUNK samples per pixel,
+        // fewer for frames so large that this would take more than DEV_SAMPLE_BYTES
+        c->sample_chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(DEV_SAMPLE_CHUNK, DEV_SAMPLE_BYTES / (n_px * sizeof(float4))));
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_samples), n_px * c->sample_chunk * sizeof(float4)));
         c->W = width; c->H = height;
         c->have_frame = true;
     }
@@ -261,12 +265,12 @@ int rt_render(rt_ctx *ctx, const rt_params *p) {
     if (n_bands > 65535u) return fail(c, RT_E_BADARG, "rt_render: too many bands for one launch");
     HIP_TRY(c, hipSetDevice(c->device));
     DevFrame fr{c->d_disc, c->d_sphere, c->d_screen, c->d_accum, c->d_ids, c->d_samples, c->d_segments};
-    // one launch per DEV_SAMPLE_CHUNK samples: the per-sample colours of a launch are staged
+    // one launch per sample_chunk samples: the per-sample colours of a launch are staged
     // in d_samples before they are added to the sums in sample order
     rt_params part = *p;
-    for (uint32_t done = 0; done < p->sample_count; done += DEV_SAMPLE_CHUNK) {
+    for (uint32_t done = 0; done < p->sample_count; done += c->sample_chunk) {
         part.sample_begin = p->sample_begin + done;
-        part.sample_count = std::min(DEV_SAMPLE_CHUNK, p->sample_count - done);
+        part.sample_count = std::min(c->sample_chunk, p->sample_count - done);
         HIP_TRY(c, rtk_launch_render(c->dsc, c->cam, part, fr, n_bands, c->stream));
     }
     return RT_OK;

@@ -70,6 +70,7 @@ struct DevScene {
     uint32_t modes;           // bit 0: some run is RUN_FLAT, bit 1: some run is RUN_TREE
 };
 #define DEV_SAMPLE_CHUNK 64u     // samples per pixel one launch renders at most (sizes DevFrame::samples)
+#define DEV_SAMPLE_BYTES (12ull << 30)   // ... as long as the staging planes stay under 12 GiB
 #define DEV_TREE_LDS_F4 2296u     // float4s of tree per workgroup (36 KB): the workgroup's LDS stays under 80 KB
 
 // Per-frame buffers and the lookup tables
