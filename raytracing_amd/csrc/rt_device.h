@@ -71,7 +71,9 @@ struct DevScene {
 };
 #define DEV_SAMPLE_CHUNK 64u     // samples per pixel one launch renders at most (sizes DevFrame::samples)
 #define DEV_SAMPLE_BYTES (12ull << 30)   // ... as long as the staging planes stay under 12 GiB
+#ifndef DEV_TREE_LDS_F4
 #define DEV_TREE_LDS_F4 2296u     // float4s of tree per workgroup (36 KB): the workgroup's LDS stays under 80 KB
+#endif
 
 // Per-frame buffers and the lookup tables
 struct DevFrame {

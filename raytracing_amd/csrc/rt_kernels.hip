@@ -860,7 +860,11 @@ template <int MODES>
 #ifndef RTK_OCC
 #define RTK_OCC 4
 #endif
-__global__ __launch_bounds__(waves_of(MODES) * 64, RTK_OCC)   // at most 128 VGPRs: four waves per SIMD
+// Two 8-wave workgroups per CU: four waves per SIMD, at most 128 VGPRs each (some per-item
+// state is spilled around the walk).  Measured alternatives on the 10,000-sphere frame: three
+// waves per SIMD without spills (one 12-wave workgroup per CU) -2 %, two waves -24 %, 4-wave
+// workgroups with a 16 KB tree copy -5 %, 96 VGPRs for five waves per SIMD -40 %.
+__global__ __launch_bounds__(waves_of(MODES) * 64, RTK_OCC)
 void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
     __shared__ Lds<MODES> lds;
     const SceneView sc = view_of(dsc, fr.segments);
@@ -937,11 +941,21 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
             }
         }
     };
+#ifdef RTK_TIMES
+    unsigned long long tm_scan = 0, tm_rest = 0;
+#endif
     if (p.max_bounces > 0) fetch(true);
 
     while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
         Hit h;
+#ifdef RTK_TIMES
+        const unsigned long long tm0 = __builtin_readcyclecounter();
+#endif
         scan_list<MODES>(sc, ray, p.t_min, alive, lds.tree[wave], lds.tree_top, h);
+#ifdef RTK_TIMES
+        const unsigned long long tm1 = __builtin_readcyclecounter();
+        tm_scan += tm1 - tm0;
+#endif
         n_seg += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(alive));
         bool done = false;
         if (alive) {
@@ -971,7 +985,14 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
             }
         }
         if (__builtin_amdgcn_ballot_w64(done) != 0ull) fetch(done);
+#ifdef RTK_TIMES
+        tm_rest += __builtin_readcyclecounter() - tm1;
+#endif
     }
+#ifdef RTK_TIMES
+    // development aid: wave time inside the closest-hit scan and outside it
+    if (lane == 0) { atomicAdd(fr.segments + 4, tm_scan); atomicAdd(fr.segments + 7, tm_rest); }
+#endif
 
     // every sample of the strip is in memory once all waves are here; each thread then adds
     // up its own pixel in sample order
