@@ -756,7 +756,7 @@ __device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, f
 // Rebuild the HitRecord of the closest hit (p, normal, front_face) exactly as
 // the primitive's hit() filled it, then run its material's scatter.
 // Returns the material index; ray is replaced by the scattered ray.
-__device__ __forceinline__ uint32_t shade_hit(const SceneView &sc, const float *tbl_sphere, Ray &ray, const Hit &h,
+__device__ __forceinline__ uint32_t shade_hit(const SceneView &sc, const float *tbl_sphere, Ray &ray, V3 ud, const Hit &h,
                                               float sp_bn, uint32_t &path_counter, uint32_t path_key,
                                               uint32_t bounce) {
     V3 p = ray.o + ray.d * h.t;   // Ray::at, src/ray/mod.rs:19-21
@@ -801,20 +801,24 @@ __device__ __forceinline__ uint32_t shade_hit(const SceneView &sc, const float *
     const f4 ma = sc.mat_albedo[mat];   // r, g, b, param
     const int mk_ = sc.mat_kind[mat];
     V3 dir;
+    // `ud` is unit_vector(r_in.direction) (src/geometry/mod.rs:276,326), the same value for
+    // whichever material needs it; the unit-sphere draw of Metal and Lambertian is one lookup
+    V3 rv = mk(0.0f, 0.0f, 0.0f);
+    if (mk_ != RT_DIELECTRIC) {
+        path_counter += 1;
+        rv = rius(tbl_sphere, path_counter, sp_bn);
+    }
     if (mk_ == RT_METAL) {
         // Metal::scatter, src/geometry/mod.rs:274-281
-        V3 reflected = reflect(unit(ray.d), normal);
-        path_counter += 1;
-        dir = reflected + rius(tbl_sphere, path_counter, sp_bn) * ma.w;
+        V3 reflected = reflect(ud, normal);
+        dir = reflected + rv * ma.w;
     } else if (mk_ == RT_LAMBERTIAN) {
         // Lambertian::scatter, src/geometry/mod.rs:287-299
-        path_counter += 1;
-        dir = normal + rius(tbl_sphere, path_counter, sp_bn);
+        dir = normal + rv;
         if (dir.x < 0.0f && dir.y < 0.0f && dir.z < 0.0f) dir = normal;   // is_near_zero, src/vector/mod.rs:29-32
     } else {
         // Dielectric::scatter, src/geometry/mod.rs:323-346
         float ratio = ff ? 1.0f / ma.w : ma.w;
-        V3 ud = unit(ray.d);
         float cos_theta = rmin(dot(-ud, normal), 1.0f);
         float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
         bool refl = ratio * sin_theta > 1.0f;
@@ -843,8 +847,7 @@ __device__ __forceinline__ uint32_t shade_hit(const SceneView &sc, const float *
 }
 
 // sky branch of ray_colour, src/raytracer.rs:81-91
-__device__ __forceinline__ V3 sky(V3 d, bool gamma) {
-    V3 ud = unit(d);
+__device__ __forceinline__ V3 sky(V3 ud, bool gamma) {
     float t = 0.5f * ud.y + 1.0f;
     V3 c = mk(1.0f, 1.0f, 1.0f) * (1.0f - t) + mk(0.5f, 0.7f, 1.0f) * t;
     if (gamma) { c.x = __builtin_sqrtf(c.x); c.y = __builtin_sqrtf(c.y); c.z = __builtin_sqrtf(c.z); }
@@ -961,17 +964,20 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
         if (alive) {
             const size_t pix_out = (size_t)(H - 1u - j) * W + i;   // src/raytracer.rs:265
             if (s == 0u && n_stack == 0u) fr.primary_ids[pix_out] = h.id;
+            // unit_vector(direction): the sky (src/raytracer.rs:82), Metal and Dielectric all start
+            // from it; computed once for the wave instead of once per branch
+            const V3 ud = unit(ray.d);
             V3 c;
             if (h.kind >= 0) {
                 uint32_t bounce = p.max_bounces - depth_left;
-                uint32_t mat = shade_hit(sc, lds.sphere, ray, h, sp_bn, path_counter, path_key, bounce);
+                uint32_t mat = shade_hit(sc, lds.sphere, ray, ud, h, sp_bn, path_counter, path_key, bounce);
                 lds.mat_stack[wave][n_stack][lane] = mat;
                 n_stack += 1;
                 depth_left -= 1;
                 done = depth_left == 0u;   // `if ray_bounces <= 0 { return 0 }`, src/raytracer.rs:69
                 c = mk(0.0f, 0.0f, 0.0f);
             } else {
-                c = sky(ray.d, gamma);
+                c = sky(ud, gamma);
                 done = true;
             }
             if (done) {
