@@ -225,6 +225,14 @@ struct Hit {
 // holder is refused here.  In a list-order scan positions only grow and the
 // extra condition never fires.
 // ----------------------------------------------------------------------
+// The tree walk does not look up the list position of every primitive it tests: it passes
+// ID_LATER, and the position is read from the by-slot table only when two hit distances tie
+// and, once, for the hit the run ends with.  (An ID_LATER holder is always a primitive of the
+// kind and run being walked: earlier runs leave real positions.)
+#define ID_LATER (-2)
+__device__ __forceinline__ int32_t list_position(const RT_CONST_AS uint32_t *by_slot, uint32_t slot, int32_t id) {
+    return id == ID_LATER ? (int32_t)by_slot[slot] : id;
+}
 // Sphere::hit, src/geometry/mod.rs:60-94; `a` is |dir|^2 (:63)
 __device__ __forceinline__ void sphere_exact(const SceneView &sc, uint32_t slot, int32_t id, const Ray &ray,
                                              float a, float t_min, Hit &h, bool &ff_shared) {
@@ -240,7 +248,7 @@ __device__ __forceinline__ void sphere_exact(const SceneView &sc, uint32_t slot,
         root = (-half_b + d_sqrt) / a;
         if (root < t_min || h.t < root) return;
     }
-    if (root == h.t && id < h.id) return;
+    if (root == h.t && list_position(sc.sph_id, slot, id) < list_position(sc.sph_id, h.slot, h.id)) return;
     h.t = root; h.kind = DEV_SPHERE; h.slot = slot; h.id = id;
     if (sc.need_ff_shared) {
         V3 p = ray.o + ray.d * root;
@@ -286,7 +294,7 @@ __device__ __forceinline__ void tri_exact(const SceneView &sc, uint32_t slot, in
         if (!(p.x >= lo.x - delta && p.x <= hi.x + delta && p.y >= lo.y - delta && p.y <= hi.y + delta &&
               p.z >= lo.z - delta && p.z <= hi.z + delta)) return;
     }
-    if (t == h.t && id < h.id) return;
+    if (t == h.t && list_position(sc.tri_id, slot, id) < list_position(sc.tri_id, h.slot, h.id)) return;
     h.t = t; h.kind = DEV_TRI; h.slot = slot; h.id = id;
     if (sc.need_ff_shared) {
         V3 outward = unit(cross(E1, E2));
@@ -516,8 +524,8 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
                     RTK_COUNT(sc, 4, 1);
                     RTK_COUNT_ANY(sc, 7, 1);
                     const uint32_t slot = run.first + idx;
-                    if (KIND == DEV_SPHERE) sphere_exact(sc, slot, (int32_t)sc.sph_id[slot], ray, a, t_min, h, ff_shared);
-                    else tri_exact(sc, slot, (int32_t)sc.tri_id[slot], ray, t_min, h, ff_shared);
+                    if (KIND == DEV_SPHERE) sphere_exact(sc, slot, ID_LATER, ray, a, t_min, h, ff_shared);
+                    else tri_exact(sc, slot, ID_LATER, ray, t_min, h, ff_shared);
                 }
             }
         };
@@ -660,6 +668,7 @@ __device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &ru
             tbl.entry_bits[lane] = (uint32_t)(h.kind + 1) | ((uint32_t)h.ff << 8) | ((uint32_t)ff_shared << 9);
         }
         walk_tree<KIND>(sc, run, cull, walking, tbl, tree_top, lds_from_level, ray, a, t_min, h, ff_shared);
+        if (walking && h.id == ID_LATER) h.id = (int32_t)(KIND == DEV_SPHERE ? sc.sph_id[h.slot] : sc.tri_id[h.slot]);
         if (walking && h.t != h.t) {
             const uint32_t bits = tbl.entry_bits[lane];
             h.t = tbl.entry_t[lane]; h.id = tbl.entry_id[lane]; h.slot = tbl.entry_slot[lane];
