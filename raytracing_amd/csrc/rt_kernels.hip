@@ -268,6 +268,9 @@ __device__ __forceinline__ void tri_exact(const SceneView &sc, uint32_t slot, in
     const f4 v0 = sc.tris[3 * slot];
     const f4 e1 = sc.tris[3 * slot + 1];
     const f4 e2 = sc.tris[3 * slot + 2];
+    // all three fetched now: left to itself the compiler fetches v0 only after the determinant
+    // test, a second round trip to memory for most triangles that get this far
+    asm volatile("" ::"v"(v0.x), "v"(e1.x), "v"(e2.x));
     V3 E1 = mk(e1.x, e1.y, e1.z), E2 = mk(e2.x, e2.y, e2.z);
     V3 hh = cross(ray.d, E2);
     float det = dot(E1, hh);
