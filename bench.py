@@ -164,7 +164,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from raytracing_amd import Renderer, load_tables, make_params
-    from raytracing_amd import workloads
+    from raytracing_amd import multi_gpu, workloads
 
     tables = load_tables()
     wl = workloads.workload(args.workload)
@@ -181,6 +181,7 @@ def main():
     r.begin_frame(w, h)
     block = torch.zeros((max_bands * 8, w), dtype=torch.int32, device="cuda")
     gathered = torch.zeros((world * max_bands * 8, w), dtype=torch.int32, device="cuda") if world > 1 else None
+    frame = [None]
 
     def step(k):
         """samples [k*sps, (k+1)*sps) modulo the frame's spp, so any number of steps is valid"""
@@ -190,10 +191,12 @@ def main():
         r.timer_start()
         r.render(p)
         ms = r.timer_stop()          # HIP events on the library's stream around the launch
+        torch.cuda.current_stream().synchronize()   # the previous step's gather has read `block`
         r.export_packed_bands(block.data_ptr(), block.numel(), rank, world)
         r.sync()
         if world > 1:
             dist.all_gather_into_tensor(gathered, block)
+            frame[0] = multi_gpu.compose(gathered.view(world, max_bands * 8, w), h)   # display order, every rank
         return ms
 
     def barrier():

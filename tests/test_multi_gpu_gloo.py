@@ -86,3 +86,16 @@ def test_compose_single_rank_is_a_vertical_flip():
     blk = torch.arange(16 * 3, dtype=torch.int32).reshape(16, 3)     # 2 bands, height 13: 3 padding rows
     out = multi_gpu.compose(blk.unsqueeze(0), 13)
     assert torch.equal(out, blk[:13].flip(0))
+
+
+@pytest.mark.parametrize("world,height", [(2, 337), (4, 1080), (8, 2160), (8, 90), (3, 8), (8, 9)])
+def test_compose_rebuilds_any_frame(world, height):
+    """blocks cut from a random frame the way rt_export_packed_bands lays them out, stacked in
+    rank order like the output of all_gather_into_tensor, compose back to the frame"""
+    import torch
+    rng = np.random.default_rng(world * 10000 + height)
+    frame = rng.integers(0, 1 << 24, size=(height, 37)).astype(np.uint32)
+    blocks = np.stack([block_from_packed(frame, r, world, height) for r in range(world)])
+    gathered = torch.from_numpy(blocks.astype(np.int64)).reshape(world * blocks.shape[1], 37)
+    out = multi_gpu.compose(gathered.view(world, blocks.shape[1], 37), height).numpy().astype(np.uint32)
+    assert np.array_equal(out, frame)
