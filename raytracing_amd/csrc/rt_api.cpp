@@ -168,7 +168,7 @@ int rt_upload_scene(rt_ctx *ctx, const rt_scene *s) {
     Ctx *c = C(ctx);
     if (!c) return RT_E_BADARG;
     if (!s) return fail(c, RT_E_BADARG, "rt_upload_scene: scene is null");
-    // RT_HIP_FLAT_SCAN=1 keeps long runs in list order (no bounding-sphere tree):
+    // RT_HIP_FLAT_SCAN=1 keeps long runs in list order (no tree):
     // the brute-force scan whose work matches the reference's linear list.
     const char *flat = std::getenv("RT_HIP_FLAT_SCAN");
     const bool use_tree = !(flat && flat[0] && flat[0] != '0');

@@ -957,7 +957,7 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
         }
     };
 #ifdef RTK_TIMES
-    unsigned long long tm_scan = 0, tm_rest = 0;
+    unsigned long long tm_scan = 0, tm_rest = 0, tm_done = 0, tm_fetch = 0;
 #endif
     if (p.max_bounces > 0) fetch(true);
 
@@ -992,24 +992,47 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
                 c = sky(ud, gamma);
                 done = true;
             }
+#ifdef RTK_TIMES
+            const unsigned long long tm2 = __builtin_readcyclecounter();
+#endif
             if (done) {
                 // attenuation * ray_colour(...), innermost product first (src/raytracer.rs:79)
-                for (uint32_t k = n_stack; k-- > 0u;) {
-                    const f4 ma = sc.mat_albedo[lds.mat_stack[wave][k][lane]];
-                    c = mk(ma.x, ma.y, ma.z) * c;
+                // (four entries per round: their fetches overlap, the products keep their order)
+                uint32_t k = n_stack;
+                while (k != 0u) {
+                    const uint32_t m0 = lds.mat_stack[wave][k - 1u][lane];
+                    const uint32_t m1 = lds.mat_stack[wave][k >= 2u ? k - 2u : 0u][lane];
+                    const uint32_t m2 = lds.mat_stack[wave][k >= 3u ? k - 3u : 0u][lane];
+                    const uint32_t m3 = lds.mat_stack[wave][k >= 4u ? k - 4u : 0u][lane];
+                    const f4 a0 = sc.mat_albedo[m0], a1 = sc.mat_albedo[m1], a2 = sc.mat_albedo[m2], a3 = sc.mat_albedo[m3];
+                    c = mk(a0.x, a0.y, a0.z) * c;
+                    if (k >= 2u) c = mk(a1.x, a1.y, a1.z) * c;
+                    if (k >= 3u) c = mk(a2.x, a2.y, a2.z) * c;
+                    if (k >= 4u) c = mk(a3.x, a3.y, a3.z) * c;
+                    k = k >= 4u ? k - 4u : 0u;
                 }
                 fr.samples[(size_t)(s - p.sample_begin) * n_px + pix_out] = make_float4(c.x, c.y, c.z, 0.0f);
                 alive = false;
             }
+#ifdef RTK_TIMES
+            tm_done += __builtin_readcyclecounter() - tm2;
+#endif
         }
+#ifdef RTK_TIMES
+        const unsigned long long tm3 = __builtin_readcyclecounter();
+#endif
         if (__builtin_amdgcn_ballot_w64(done) != 0ull) fetch(done);
 #ifdef RTK_TIMES
+        tm_fetch += __builtin_readcyclecounter() - tm3;
         tm_rest += __builtin_readcyclecounter() - tm1;
 #endif
     }
 #ifdef RTK_TIMES
     // development aid: wave time inside the closest-hit scan and outside it
-    if (lane == 0) { atomicAdd(fr.segments + 4, tm_scan); atomicAdd(fr.segments + 7, tm_rest); }
+    if (lane == 0) {
+        atomicAdd(fr.segments + 4, tm_scan); atomicAdd(fr.segments + 7, tm_rest);
+        atomicAdd(fr.segments + 5, tm_done); atomicAdd(fr.segments + 6, tm_fetch);
+    }
 #endif
 
     // every sample of the strip is in memory once all waves are here; each thread then adds
