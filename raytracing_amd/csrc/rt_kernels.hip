@@ -908,17 +908,25 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
     const uint32_t strip_px = waves_of(MODES) * 64u;
     const uint32_t n_items = strip_px * p.sample_count;
 
-    uint32_t q = 0, s = 0, i = 0, j = 0;   // this lane's item: pixel of the strip, sample, column, row from the bottom
-    float sp_bn = 0.0f;
+    // Per-lane state that lives across the scan is kept small (registers are what limits the
+    // kernel): the work item, the ray, the depth budget and the unit-sphere counter.  Pixel,
+    // sample, screen-space noise value and the path's hash key are derived from the item
+    // again where they are needed.
+    uint32_t item = 0;        // this lane's work item: pixel of the strip + strip_px * (sample - sample_begin)
     bool alive = false;
     Ray ray;
     ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1);
-    uint32_t depth_left = p.max_bounces, n_stack = 0, path_key = 0, path_counter = 0;
+    uint32_t depth_left = p.max_bounces, path_counter = 0;
     uint32_t n_seg = 0;
+    auto column_of = [&](uint32_t it) { const uint32_t q = it % strip_px; return x0 + (q >> 6) * TILE + (q & 7u); };
+    auto row_of = [&](uint32_t it) { const uint32_t q = it % strip_px; return y0 + ((q >> 3) & 7u); };   // from the bottom
+    auto sample_of = [&](uint32_t it) { return p.sample_begin + it / strip_px; };
+    auto path_key_of = [&](uint32_t it) {
+        return mix32((row_of(it) * W + column_of(it)) ^ mix32(sample_of(it) ^ (p.seed * GOLDEN32)));
+    };
 
     auto start_sample = [&]() {
-        // BlueNoise::get_screenspace, src/denoising/mod.rs:19-23: fixed per pixel
-        sp_bn = fr.tbl_screen[128u * (i % 128u) + (j % 128u)];
+        const uint32_t i = column_of(item), j = row_of(item), s = sample_of(item);
         // two disc draws per sample: jitter then lens (src/raytracer.rs:254,258);
         // sample n of a single-thread run uses entries 2n+1 and 2n+2 of the
         // pre-incremented counter (src/denoising/mod.rs:13-17)
@@ -930,10 +938,8 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
         float u = ((float)i + ox) / (float)(W - 1u);
         float v = ((float)j + oy) / (float)(H - 1u);
         ray = get_ray(cam, u, v, la, lb);
-        path_key = mix32(pix ^ mix32(s ^ (p.seed * GOLDEN32)));
-        path_counter = path_key;
+        path_counter = path_key_of(item);
         depth_left = p.max_bounces;
-        n_stack = 0;
     };
     // lanes with `need` take the next items; lanes left without one stay idle for good
     auto fetch = [&](bool need) {
@@ -948,11 +954,8 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
             const uint32_t k = base + rank;
             if (need && k < n_items) {
-                q = k % strip_px;
-                s = p.sample_begin + k / strip_px;
-                i = x0 + (q >> 6) * TILE + (q & 7u);
-                j = y0 + ((q >> 3) & 7u);
-                if (i < W && j < H) { start_sample(); need = false; alive = true; }
+                item = k;
+                if (column_of(k) < W && row_of(k) < H) { start_sample(); need = false; alive = true; }
             }
         }
     };
@@ -974,17 +977,21 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
         n_seg += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(alive));
         bool done = false;
         if (alive) {
+            const uint32_t i = column_of(item), j = row_of(item), s = sample_of(item);
+            const uint32_t n_stack = p.max_bounces - depth_left;   // hits of this path so far
             const size_t pix_out = (size_t)(H - 1u - j) * W + i;   // src/raytracer.rs:265
+            // BlueNoise::get_screenspace, src/denoising/mod.rs:19-23: fixed per pixel
+            const float sp_bn = fr.tbl_screen[128u * (i % 128u) + (j % 128u)];
             if (s == 0u && n_stack == 0u) fr.primary_ids[pix_out] = h.id;
             // unit_vector(direction): the sky (src/raytracer.rs:82), Metal and Dielectric all start
             // from it; computed once for the wave instead of once per branch
             const V3 ud = unit(ray.d);
             V3 c;
+            uint32_t n_hits = n_stack;
             if (h.kind >= 0) {
-                uint32_t bounce = p.max_bounces - depth_left;
-                uint32_t mat = shade_hit(sc, lds.sphere, ray, ud, h, sp_bn, path_counter, path_key, bounce);
+                uint32_t mat = shade_hit(sc, lds.sphere, ray, ud, h, sp_bn, path_counter, path_key_of(item), n_stack);
                 lds.mat_stack[wave][n_stack][lane] = mat;
-                n_stack += 1;
+                n_hits = n_stack + 1u;
                 depth_left -= 1;
                 done = depth_left == 0u;   // `if ray_bounces <= 0 { return 0 }`, src/raytracer.rs:69
                 c = mk(0.0f, 0.0f, 0.0f);
@@ -992,13 +999,10 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
                 c = sky(ud, gamma);
                 done = true;
             }
-#ifdef RTK_TIMES
-            const unsigned long long tm2 = __builtin_readcyclecounter();
-#endif
             if (done) {
                 // attenuation * ray_colour(...), innermost product first (src/raytracer.rs:79)
                 // (four entries per round: their fetches overlap, the products keep their order)
-                uint32_t k = n_stack;
+                uint32_t k = n_hits;
                 while (k != 0u) {
                     const uint32_t m0 = lds.mat_stack[wave][k - 1u][lane];
                     const uint32_t m1 = lds.mat_stack[wave][k >= 2u ? k - 2u : 0u][lane];
