@@ -15,7 +15,7 @@ enum { DEV_SPHERE = 0, DEV_PLANE = 1, DEV_CUBE = 2, DEV_TRI = 3 };
 enum { RUN_EXACT = 0, RUN_FLAT = 1, RUN_TREE = 2 };
 // sphere runs at least this long go through the conservative rejection test
 #define DEV_CULL_MIN_RUN 32u
-// sphere / triangle runs at least this long get the bounding-sphere tree
+// sphere / triangle runs at least this long get the box tree
 #define DEV_TREE_MIN_RUN 64u
 #define DEV_MAX_LEVELS 8u
 

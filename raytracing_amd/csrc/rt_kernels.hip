@@ -1,16 +1,20 @@
 // rt_kernels.hip - the render loop as gfx950 (CDNA4, wave64) kernels.
 //
-// One wavefront renders one 8x8 pixel tile, one lane per pixel.  A lane walks
-// its samples one after the other; as soon as a path ends (sky or depth budget)
-// the lane starts its next sample, so a wave stays full until the tail of the
-// sample range.  The closest-hit scan runs over the primitive list in the
-// reference's insertion order with a wave-uniform loop counter: primitive data
-// is read through scalar loads into SGPRs and every lane tests the same
-// primitive against its own ray, so the scan has no divergence between lanes
-// that are tracing.  Arithmetic that decides a result is plain f32 mul/add/div/
-// sqrt without contraction (the reference is scalar Rust f32,
-// src/vector/mod.rs:141-189); fused multiply-add is used only in the
-// conservative sphere rejection test, which can never change a result.
+// A workgroup renders a strip of 8x8 pixel tiles of one 8-row band.  Its work items are
+// (pixel, sample) pairs handed out through one LDS counter: as soon as a lane's path ends
+// (sky or depth budget) it takes the next item, whatever pixel that belongs to, so waves stay
+// full until the strip runs out of items; the per-sample colours are staged in memory and
+// added to each pixel's sum in sample order at the end.
+// The closest-hit scan follows the primitive list in the reference's insertion order, run by
+// run (maximal stretches of one primitive kind).  Short runs: a wave-uniform loop, primitive
+// data read through scalar loads, every lane tests the same primitive against its own ray - no
+// divergence between lanes that are tracing.  Long runs of spheres or triangles: each lane
+// walks an implicit 8-ary tree of bounding boxes for its own ray and runs the exact test only
+// on what it cannot reject; equal hit distances are resolved by list position, so the result
+// is that of the list-order scan.
+// Arithmetic that decides a result is plain f32 mul/add/div/sqrt without contraction (the
+// reference is scalar Rust f32, src/vector/mod.rs:141-189); fused multiply-add is used only in
+// the conservative rejection tests (balls, boxes), which can never change a result.
 //
 // Reference lines each device function follows are cited at the function.
 #include <hip/hip_runtime.h>
@@ -217,7 +221,7 @@ struct Hit {
 // ----------------------------------------------------------------------
 // Exact primitive tests.  They update (h.t, h.kind, h.slot, h.id) like the
 // reference's list loop updates closest_so_far and its record.  A scan that
-// does not visit a run in list order (the bounding-sphere tree) must still
+// does not visit a run in list order (the tree walk) must still
 // end with the primitive the list-order scan ends with: among equal hit
 // distances the reference keeps the LATER sphere / plane / triangle
 // (`t_max < root` rejects, equality accepts, src/geometry/mod.rs:74,116), so

@@ -8,10 +8,11 @@
 //   RUN_FLAT   (spheres) list order, but eight spheres per step first go through
 //              a conservative rejection test on packed FMAs;
 //   RUN_TREE   (spheres, triangles) the run is re-ordered by recursive median
-//              splits and an implicit 8-ary tree is laid over it (bounding boxes above,
-//              the rejection test on the primitives' own balls at the leaves).  Ties between equal hit
-//              distances are resolved by list position explicitly, so the result
-//              equals the list-order scan.
+//              splits and an implicit 8-ary tree of bounding boxes is laid over it
+//              (spheres: the rejection test on their own balls at the leaves;
+//              triangles: their gate boxes).  Ties between equal hit distances are
+//              resolved by list position explicitly, so the result equals the
+//              list-order scan.
 #include "rt_scene_build.h"
 
 #include <algorithm>

@@ -1,4 +1,4 @@
-"""GPU parity for long runs (the bounding-ball tree and the list-order
+"""GPU parity for long runs (the box tree and the list-order
 rejection scan) against the CPU oracle, on inputs chosen to break a tree that
 is not exactly equivalent to the reference's insertion-ordered scan
 (HittableList::hit, src/geometry/mod.rs:240-258): exact ties, extreme size
@@ -220,7 +220,7 @@ def test_nan_closest_hit_entering_tree_runs(renderer, oracle, tables):
 
 def test_nan_and_infinite_primitives_in_tree_runs(renderer, oracle, tables):
     """NaN centres (hit by every ray with t = NaN), infinite radii, coordinates of 1e19 and
-    1e30 inside long runs: none of them may poison the bounding balls of their neighbours"""
+    1e30 inside long runs: none of them may poison the bounding volumes of their neighbours"""
     rng = np.random.default_rng(12)
     n = 200
     c = rng.uniform(-3, 3, (n, 3)).astype(f32)
