@@ -8,7 +8,7 @@
 //
 //   rt_main [--width 600] [--spp 1] [--frames 10] [--aperture 0] [--bounces 10]
 //           [--no-gamma] [--seed 0] [--device 0] [--data DIR] [--out PREFIX]
-//           [--obj FILE [--obj-scale S] [--obj-at X Y Z]] [--chunk N] [--quiet] [--png]
+//           [--obj FILE [--obj-scale S] [--obj-at X Y Z]] [--spheres N] [--chunk N] [--quiet] [--png]
 //
 // PREFIX_0000.ppm ... (.png with --png) are written when --out is given.  --chunk N renders the
 // samples of a frame N at a time (progressive); the picture is the same.
@@ -24,7 +24,7 @@
 namespace {
 
 struct Options {
-    uint32_t width = 600, spp = 1, frames = 10, bounces = 10, seed = 0, chunk = 0;
+    uint32_t width = 600, spp = 1, frames = 10, bounces = 10, seed = 0, chunk = 0, spheres = 0;
     int device = 0;
     float aperture = 0.f, obj_scale = 1.f;
     rt::vec3 obj_at{0.f, 0.f, 0.f};
@@ -37,7 +37,7 @@ struct Options {
     std::fprintf(stderr,
                  "usage: rt_main [--width W] [--spp N] [--frames F] [--aperture A] [--bounces B] [--no-gamma]\n"
                  "               [--seed S] [--device D] [--data DIR] [--out PREFIX] [--chunk N] [--quiet] [--png]\n"
-                 "               [--obj FILE [--obj-scale S] [--obj-at X Y Z]]\n");
+                 "               [--obj FILE [--obj-scale S] [--obj-at X Y Z]] [--spheres N]\n");
     std::exit(2);
 }
 
@@ -53,6 +53,7 @@ Options parse(int argc, char** argv) {
         else if (a == "--frames") { need(i, 1); o.frames = (uint32_t)std::strtoul(argv[++i], nullptr, 10); }
         else if (a == "--bounces") { need(i, 1); o.bounces = (uint32_t)std::strtoul(argv[++i], nullptr, 10); }
         else if (a == "--seed") { need(i, 1); o.seed = (uint32_t)std::strtoul(argv[++i], nullptr, 10); }
+        else if (a == "--spheres") { need(i, 1); o.spheres = (uint32_t)std::strtoul(argv[++i], nullptr, 10); }
         else if (a == "--chunk") { need(i, 1); o.chunk = (uint32_t)std::strtoul(argv[++i], nullptr, 10); }
         else if (a == "--device") { need(i, 1); o.device = std::atoi(argv[++i]); }
         else if (a == "--aperture") { need(i, 1); o.aperture = std::strtof(argv[++i], nullptr); }
@@ -97,7 +98,9 @@ int main(int argc, char** argv) {
         const std::vector<float> screen = rt::load_table(o.data + "/screenspace_blue_noise_128x128.txt", 16384);
 
         rt::Scene world;
-        rt::HittableList scene = rt::Scene::get_scene();
+        // --spheres N: the synthetic benchmark scene (N random spheres on a plane, fixed camera)
+        // instead of the reference's scene and dolly
+        rt::HittableList scene = o.spheres ? rt::random_spheres(o.spheres) : rt::Scene::get_scene();
         if (!o.obj.empty()) {
             size_t n = rt::load_obj(o.obj, scene, rt::Lambertian({0.2f, 0.25f, 0.6f}), o.obj_scale, o.obj_at);
             if (!o.quiet) std::printf("INFO: %zu triangles from %s\n", n, o.obj.c_str());
@@ -112,7 +115,7 @@ int main(int argc, char** argv) {
         uint64_t total_segments = 0;
         double total_ms = 0.0;
         for (uint32_t frame = 0; frame < o.frames; ++frame) {
-            const rt::Camera cam = world.get_camera(o.aperture, o.spp);
+            const rt::Camera cam = o.spheres ? rt::random_spheres_camera(o.spp) : world.get_camera(o.aperture, o.spp);
             check(ctx, rt_set_camera(ctx, &cam.c), "rt_set_camera");
             const auto start_time = std::chrono::steady_clock::now();
             check(ctx, rt_begin_frame(ctx, image_width, image_height), "rt_begin_frame");

@@ -6,6 +6,7 @@
 // Building the list is all that happens here; no intersection or shading code.
 #pragma once
 
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -165,6 +166,61 @@ public:
     }
     void move_cam() { counter = (counter + 1) % 100; }
 };
+
+// ---- synthetic benchmark scene ------------------------------------------------
+// PCG-XSH-RR 64/32 (O'Neill), the generator the benchmark scenes draw from
+class Pcg32 {
+public:
+    explicit Pcg32(uint64_t seed, uint64_t seq = 54) : state_(0), inc_((seq << 1) | 1) {
+        next_u32();
+        state_ += seed;
+        next_u32();
+    }
+    uint32_t next_u32() {
+        const uint64_t old = state_;
+        state_ = old * 6364136223846793005ull + inc_;
+        const uint32_t xs = (uint32_t)(((old >> 18) ^ old) >> 27);
+        const uint32_t rot = (uint32_t)(old >> 59);
+        return (xs >> rot) | (xs << ((32 - rot) & 31));
+    }
+    double uniform(double lo = 0.0, double hi = 1.0) { return lo + (hi - lo) * (double)(next_u32() >> 8) * (1.0 / 16777216.0); }
+
+private:
+    uint64_t state_, inc_;
+};
+
+// n non-overlapping spheres resting on the plane y = 0: centres uniform in x, z in
+// [-extent, extent], radius uniform [0.1, 0.4]; 60 % Lambertian, 30 % Metal (fuzz U[0, 0.5]),
+// 10 % Dielectric 1.5; albedo U[0.1, 0.9]^3.  List order: the spheres, then the ground plane
+// (Lambertian 0.5 grey).  The same draws in the same order as the Python workload generator.
+inline HittableList random_spheres(uint32_t n = 10000, uint64_t seed = 1234, double extent = 30.0) {
+    Pcg32 rng(seed);
+    std::vector<double> cx, cz, rr;
+    HittableList list;
+    while (cx.size() < n) {
+        const double x = rng.uniform(-extent, extent), z = rng.uniform(-extent, extent), r = rng.uniform(0.1, 0.4);
+        bool overlap = false;
+        for (size_t k = 0; k < cx.size() && !overlap; ++k) {
+            const double d2 = (cx[k] - x) * (cx[k] - x) + (cz[k] - z) * (cz[k] - z) + (rr[k] - r) * (rr[k] - r);
+            overlap = d2 < (rr[k] + r) * (rr[k] + r);
+        }
+        if (overlap) continue;
+        cx.push_back(x); cz.push_back(z); rr.push_back(r);
+        const double m = rng.uniform();
+        const double ar = rng.uniform(0.1, 0.9), ag = rng.uniform(0.1, 0.9), ab = rng.uniform(0.1, 0.9);
+        const colour albedo{(float)ar, (float)ag, (float)ab};
+        Material mat = Lambertian(albedo);
+        if (m >= 0.9) mat = Dielectric(albedo, 1.5f);
+        else if (m >= 0.6) mat = Metal(albedo, (float)rng.uniform(0.0, 0.5));
+        list.add(Sphere{{(float)x, (float)r, (float)z}, (float)r, mat});
+    }
+    list.add(Plane{{0.0f, 1.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, Lambertian({0.5f, 0.5f, 0.5f}), true});
+    return list;
+}
+inline Camera random_spheres_camera(uint32_t samples_per_px) {
+    const float focus = (float)std::sqrt(0.0 * 0.0 + 6.0 * 6.0 + 25.0 * 25.0);
+    return Camera::make(27.0f, 16.0f / 9.0f, 0.0f, focus, {0.0f, 6.0f, 25.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 1.0f, 0.0f}, samples_per_px);
+}
 
 // ---- Wavefront .obj --------------------------------------------------------
 // `v x y z` and `f a b c ...` records; indices are 1-based, negative indices

@@ -23,7 +23,9 @@ static void ul(const char* name, const uint32_t* p, uint32_t n) {
 }
 
 int main(int argc, char** argv) {
-    rt::HittableList list = rt::Scene::get_scene();
+    rt::HittableList list = (argc == 3 && std::string(argv[1]) == "spheres")
+                                ? rt::random_spheres((uint32_t)std::strtoul(argv[2], nullptr, 10))
+                                : rt::Scene::get_scene();
     if (argc == 6) {
         rt::load_obj(argv[1], list, rt::Metal({0.5f, 0.25f, 0.125f}, 0.3f), std::strtof(argv[2], nullptr),
                      {std::strtof(argv[3], nullptr), std::strtof(argv[4], nullptr), std::strtof(argv[5], nullptr)});
@@ -44,6 +46,10 @@ int main(int argc, char** argv) {
     ul("mat_kind", reinterpret_cast<const uint32_t*>(s.mat_kind), s.n_materials);
     fl("mat_r", s.mat_r, s.n_materials); fl("mat_g", s.mat_g, s.n_materials); fl("mat_b", s.mat_b, s.n_materials);
     fl("mat_param", s.mat_param, s.n_materials);
+    {
+        rt::Camera cam = rt::random_spheres_camera(256);
+        fl("spheres_camera", reinterpret_cast<const float*>(&cam.c), 19);
+    }
     // camera of the dolly at COUNTER = 0, 1, 99 and after wrapping
     rt::Scene world;
     for (int k = 0; k < 101; ++k) {

@@ -111,6 +111,21 @@ def test_cpp_mirror_equals_python_mirror(tmp_path):
         assert dump[("counter", counter)] == bits
 
 
+def test_cpp_benchmark_scene_equals_python_generator(tmp_path):
+    """rt::random_spheres (same PCG32 stream, same rejection sampling) against workloads.random_spheres"""
+    from raytracing_amd import workloads
+    dump = _dump_scene(tmp_path, ["spheres", 600])
+    flat = workloads.random_spheres(600)
+    for name, arr in flat.arrays.items():
+        if arr.dtype == np.float32:
+            expect = ["%08x" % b for b in arr.view(np.uint32)]
+        else:
+            expect = [str(int(v)) for v in arr.view(np.uint32)]
+        assert dump[name] == expect, name
+    cam = workloads.random_spheres_camera(256)
+    assert dump["spheres_camera"] == ["%08x" % b for b in np.frombuffer(bytes(cam.struct), dtype=np.uint32)[:19]]
+
+
 def test_driver_fails_loudly_without_gpu_or_with_bad_arguments():
     exe = os.path.join(PKG, "rt_main")
     assert os.path.exists(exe), "build the driver first: make -C raytracing_amd/csrc"
@@ -172,3 +187,28 @@ def test_driver_with_obj_mesh_equals_oracle(tmp_path, oracle, tables):
     assert n == len(tris)
     acc, _, _ = oracle.render(scene.flatten(), oracle.scene_camera(0, 0.0), tables, make_params(w, h, spp=spp))
     assert np.array_equal(_read_ppm(str(tmp_path / "m_0000.ppm")), oracle.pack(acc))
+
+
+@pytest.mark.gpu
+def test_driver_benchmark_scene_equals_oracle(tmp_path, oracle, tables):
+    """rt_main --spheres 10000: the C++ generator, the tree scan and the PNG writer"""
+    import struct
+    import zlib
+    from raytracing_amd import workloads
+    exe = os.path.join(PKG, "rt_main")
+    w, spp = 96, 2
+    h = image_height(w)
+    subprocess.check_output([exe, "--width", str(w), "--spp", str(spp), "--frames", "1", "--spheres", "10000", "--png",
+                             "--data", os.path.join(PKG, "data"), "--out", str(tmp_path / "s"), "--quiet"],
+                            text=True, timeout=100)
+    wl = workloads.workload("c4")
+    acc, _, _ = oracle.render(wl["flat"], wl["camera"], tables, make_params(w, h, spp=spp), threads=16)
+    raw = (tmp_path / "s_0000.png").read_bytes()
+    pos, idat = 8, b""
+    while pos < len(raw):
+        n, typ = struct.unpack(">I4s", raw[pos:pos + 8])
+        if typ == b"IDAT":
+            idat += raw[pos + 8:pos + 8 + n]
+        pos += 12 + n
+    pix = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(h, w * 3 + 1)[:, 1:].reshape(h, w, 3).astype(np.uint32)
+    assert np.array_equal((pix[..., 0] << 16) | (pix[..., 1] << 8) | pix[..., 2], oracle.pack(acc))
