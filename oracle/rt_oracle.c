@@ -500,6 +500,11 @@ typedef struct {
     float t_min;
 } trace_env;
 
+/* Optional log of the segments of one path (orc_path below): 9 floats per
+ * segment {origin, direction, hit(0/1), list index, t}. */
+static __thread float *path_log = NULL;
+static __thread uint32_t path_log_cap = 0, path_log_n = 0;
+
 /* ray_colour, src/raytracer.rs:68-92 */
 static vec3 ray_colour(const trace_env *env, const ray_t *ray, uint32_t ray_bounces, uint32_t pi,
                        uint32_t pj, int32_t *first_id) {
@@ -513,6 +518,12 @@ static vec3 ray_colour(const trace_env *env, const ray_t *ray, uint32_t ray_boun
     sm->segments += 1;
     int got = list_hit(env->sc, ray, &attenuation, env->t_min, INFINITY, &hr, &r, &idx, sm, pi, pj);
     if (first_id) *first_id = got ? idx : -1;
+    if (path_log && path_log_n < path_log_cap) {
+        float *e = path_log + 9 * path_log_n++;
+        e[0] = ray->origin.x; e[1] = ray->origin.y; e[2] = ray->origin.z;
+        e[3] = ray->dir.x; e[4] = ray->dir.y; e[5] = ray->dir.z;
+        e[6] = (float)got; e[7] = (float)idx; e[8] = hr.t;
+    }
     if (got) {
         if (sm->mode == ORC_MODE_DET) {
             int32_t k = env->sc->mats[env->sc->list[idx].mat].kind;
@@ -777,6 +788,47 @@ int orc_trace_one(const rt_scene *scene, const float *sphere_tbl, const float *s
     out16[13] = att.x; out16[14] = att.y; out16[15] = att.z;
     scene_free(&sc);
     return RT_OK;
+}
+
+/*
+ * The segments of one path of the deterministic schedule: pixel (i, j counted
+ * from the bottom), sample s.  out takes 9 floats per segment {origin,
+ * direction, hit(0/1), list index, t}; returns the number of segments, or a
+ * negative RT_E_*.  colour3 (may be NULL) receives the path's colour.
+ */
+int orc_path(const rt_scene *scene, const rt_camera *cam, const float *disc, const float *sphere,
+             const float *screen, const rt_params *params, uint32_t i, uint32_t j, uint32_t s,
+             float *out, uint32_t cap, float *colour3) {
+    if (!scene || !cam || !disc || !sphere || !screen || !params || !out) return RT_E_BADARG;
+    if (params->width < 2 || params->height < 2 || i >= params->width || j >= params->height ||
+        params->max_bounces > RT_MAX_BOUNCES)
+        return RT_E_BADARG;
+    scene_t sc;
+    int rc = scene_build(scene, &sc);
+    if (rc != RT_OK) return rc;
+    sampler_t sm;
+    memset(&sm, 0, sizeof sm);
+    sm.mode = ORC_MODE_DET;
+    sm.disc = disc; sm.sphere = sphere; sm.screen = screen;
+    const uint32_t W = params->width, H = params->height;
+    uint64_t n = ((uint64_t)j * W + i) * params->spp + s;
+    sm.counter_disc = (uint32_t)(2u * n);
+    sm.path_key = mix32((j * W + i) ^ mix32(s ^ (params->seed * GOLDEN32)));
+    sm.path_counter = sm.path_key;
+    trace_env env = {&sc, &sm, params->max_bounces, params->gamma != 0, params->t_min};
+    float ox, oy, a, b;
+    random_in_disc(&sm, &ox, &oy);
+    float u = ((float)i + ox) / (float)(W - 1);
+    float v = ((float)j + oy) / (float)(H - 1);
+    random_in_disc(&sm, &a, &b);
+    ray_t r = get_ray(cam, u, v, v3(a, b, 0.0f));
+    path_log = out; path_log_cap = cap; path_log_n = 0;
+    vec3 c = ray_colour(&env, &r, params->max_bounces, i, j, NULL);
+    int got = (int)path_log_n;
+    path_log = NULL; path_log_cap = 0;
+    if (colour3) { colour3[0] = c.x; colour3[1] = c.y; colour3[2] = c.z; }
+    scene_free(&sc);
+    return got;
 }
 
 /* Camera::get_ray for the known-answer tests: out6 = origin, dir */

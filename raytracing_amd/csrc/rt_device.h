@@ -22,10 +22,10 @@ enum { RUN_EXACT = 0, RUN_FLAT = 1, RUN_TREE = 2 };
 // One maximal run of same-kind primitives of the reference's insertion-ordered
 // Vec<Box<dyn Hittable>> (src/geometry/mod.rs:228-238).  128 bytes, read with two
 // scalar loads.  A RUN_FLAT run has its rejection records in DevScene::cull_rec (steps of
-// eight records, 128 bytes).  A RUN_TREE run has an implicit 8-ary tree in
-// DevScene::tree_rec: level 0 holds the primitives' own ball records in steps of eight
-// (10 float4), level L+1 one bounding box per step of level L, again in steps of eight
-// (12 float4); the children of step s of level L+1 are steps 8s..8s+7 of level L.
+// eight records, 128 bytes).  A RUN_TREE run has an implicit 8-ary tree of boxes in
+// DevScene::tree_rec: level 0 holds one box per primitive in steps of eight (12 float4),
+// level L+1 one bounding box per step of level L, again in steps of eight; the children of
+// step s of level L+1 are steps 8s..8s+7 of level L.
 struct DevRun {
     uint32_t kind;        // DEV_*
     uint32_t first;       // first slot in the kind's arrays
@@ -36,9 +36,9 @@ struct DevRun {
     uint32_t top_steps;   // steps of the top level (RUN_FLAT: all steps, an even number)
     uint32_t order_base;  // DevScene::order + order_base: list position in run -> slot offset
     uint32_t level_base[DEV_MAX_LEVELS];   // RUN_TREE: float4 offset of each level in tree_rec; RUN_FLAT: [0] = first step
-    uint32_t level_aux[DEV_MAX_LEVELS];    // [0]: float bits of 1 - eps of the ball records; [L>0]: boxes at level L
+    uint32_t level_aux[DEV_MAX_LEVELS];    // RUN_TREE: boxes at each level; RUN_FLAT: [0] = float bits of 1 - eps
     float reach;          // RUN_TREE: max over bounded balls of |centre| + radius
-    float inv_2rho;       // RUN_TREE of spheres: 1 / (2 * smallest |radius|), +inf when that is 0
+    float inv_2rho;       // RUN_TREE of spheres: 1 / (2 * smallest |radius|), +inf when that is 0 or for triangles
     uint32_t pad[6];
 };
 
@@ -58,8 +58,7 @@ struct DevScene {
     const uint32_t *tri_id;   // list position                       (by slot)
     const float4 *cull_rec;   // RUN_FLAT rejection records, 8 float4 per step of eight balls:
                               // four pairs {cx0,cx1, cy0,cy1}{cz0,cz1, thr0,thr1}
-    const float4 *tree_rec;   // RUN_TREE records.  Ball step, 10 float4: {cx0,cx1,cy0,cy1} x4,
-                              // {cz0,cz1,thr0,thr1} x4, {r0..r3}, {r4..r7}.  Box step, 12 float4:
+    const float4 *tree_rec;   // RUN_TREE records, 12 float4 per step of eight boxes:
                               // per pair of boxes {lo0,lo1,hi0,hi1} for x, y, z
     const uint32_t *order;    // see DevRun::order_base
     const float4 *mat_albedo; // r, g, b, param

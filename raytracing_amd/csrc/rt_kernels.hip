@@ -89,7 +89,7 @@ struct SceneView {
     const RT_CONST_AS u16v *runs;         // two per DevRun
     const RT_CONST_AS f4 *sph_geom, *planes, *cubes, *tris, *mat_albedo;
     const RT_CONST_AS f16 *cull_rec;      // RUN_FLAT: two per step of eight records
-    const RT_CONST_AS f4 *tree_rec;       // RUN_TREE: ten per step of eight balls, twelve per step of eight boxes
+    const RT_CONST_AS f4 *tree_rec;       // RUN_TREE: twelve per step of eight boxes
     const RT_CONST_AS uint32_t *sph_mat, *sph_id, *tri_id, *order;
     const RT_CONST_AS int32_t *mat_kind;
     uint32_t n_runs, need_ff_shared;
@@ -139,7 +139,7 @@ constexpr int TILE = 8;   // 8x8 pixels per wavefront
 
 struct TreeTable {
     uint32_t base[DEV_MAX_LEVELS];    // float4 offset of each level in tree_rec
-    uint32_t count[DEV_MAX_LEVELS];   // boxes at each level above the leaves
+    uint32_t count[DEV_MAX_LEVELS];   // boxes at each level
     // closest-hit state of every lane when it entered the run being walked, for the lanes
     // that have to start the run over in list order
     float entry_t[64];
@@ -325,7 +325,10 @@ __device__ __forceinline__ void tri_exact(const SceneView &sc, uint32_t slot, in
 // spare.  Bounding balls of the tree use larger eps (see the host-side
 // builder); eps enters through thr and through the per-level factor `keep`.
 // The test never ACCEPTS anything: survivors run the exact test itself.
-// NaN or infinite intermediates compare false and survive.
+// NaN intermediates compare false and survive.  The bounds above are relative
+// ones and need finite, normal intermediates: a ray whose |d|^2 leaves
+// (1e-12, 1e12) or whose |o|^2 reaches 1e36 (Sphere::hit then works with
+// infinities and accepts NaN roots) gets |o|^2 = NaN and rejects nothing.
 // ----------------------------------------------------------------------
 struct Cull { float ux, uy, uz, nou, ax, ay, az, oo; };
 
@@ -336,6 +339,7 @@ __device__ __forceinline__ Cull cull_setup(const Ray &ray, float a) {
     c.nou = -__builtin_fmaf(ray.o.x, c.ux, __builtin_fmaf(ray.o.y, c.uy, ray.o.z * c.uz));
     c.ax = -2.0f * ray.o.x; c.ay = -2.0f * ray.o.y; c.az = -2.0f * ray.o.z;
     c.oo = __builtin_fmaf(ray.o.x, ray.o.x, __builtin_fmaf(ray.o.y, ray.o.y, ray.o.z * ray.o.z));
+    if (!(a > 1e-12f && a < 1e12f && c.oo < 1e36f)) c.oo = __builtin_nanf("");
     return c;
 }
 // g of two balls at once: seven v_pk_fma_f32, each taking one SGPR pair (the
@@ -441,19 +445,16 @@ __device__ __forceinline__ void scan_flat(const SceneView &sc, const RunView &ru
 
 // ----------------------------------------------------------------------
 // RUN_TREE: the run's primitives are stored in a spatially hierarchical order under an
-// implicit 8-ary tree.  Level 0 holds the primitives' own records in steps of eight (balls
-// for spheres, gate boxes for triangles), level L+1 one bounding box per step of level L
-// (the children of step s of level L+1 are the steps 8s..8s+7 one level down).  Every lane
-// walks the tree for its own ray.  No stack: the path is the step index itself
+// implicit 8-ary tree of axis-aligned boxes.  Level 0 holds one box per primitive in steps of
+// eight (a sphere's extent, a triangle's gate box), level L+1 one bounding box per step of
+// level L (the children of step s of level L+1 are the steps 8s..8s+7 one level down).  Every
+// lane walks the tree for its own ray.  No stack: the path is the step index itself
 // (parent = s >> 3), the children still to visit are one byte per level in a 64-bit register.
 //
-// Box step: a lane fetches ITS node (192 bytes), tests the eight child boxes and descends
-// into the survivor the ray enters first; on the triangles' leaf level the survivors get the
-// exact test instead.  Ball step (spheres' leaf level): the eight balls of the step go
-// through the rejection test, survivors get the exact test.  A wave of a sphere tree has
-// lanes of both kinds; each trip it runs one kind (a ball step once half as many lanes wait for
-// one as for a box step), the others sit the trip out.  After a leaf step, or when no child survives, a lane moves on to its next
-// pending node; the walk ends when a ballot says no lane has a node left.
+// Per trip a lane fetches ITS node (192 bytes), tests the eight child boxes and descends into
+// the survivor the ray enters first; on level 0 the survivors get the exact test instead.
+// When no child survives, or after a leaf step, the lane moves on to its next pending node;
+// the walk ends when a ballot says no lane has a node left.
 //
 // A child box [lo, hi] is skipped when the ray misses the box widened by `pad` on every
 // side, lies behind the origin, or starts beyond closest_so_far (slab test:
@@ -468,13 +469,10 @@ __device__ __forceinline__ void scan_flat(const SceneView &sc, const RunView &ru
 //       to is off by < 4 ulp S;
 //   (b) each t is off by a few ulp of (|plane| + |o| + pad) |1/d|, i.e. the plane by a few
 //       ulp of S.  2^-17 S covers (b) and the triangles' (a) three times over.
-// A ball of the spheres' leaf level is skipped when
-//   |o|^2 keep - 2 o.c - max((c-o).u, 0)^2 > thr          (misses sideways / lies behind)
-//   (c-o).u - R > closest_so_far * |d| + slack             (lies beyond the best hit)
 // A lane leaves the walk as soon as its closest_so_far turns NaN (see scan_tree).
 // ----------------------------------------------------------------------
 template <int KIND>
-__device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &run, const Cull &cull, bool walking,
+__device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &run, bool walking,
                                           TreeTable &tbl, const f4 *tree_top, uint32_t lds_from_level,
                                           const Ray &ray, float a, float t_min, Hit &h, bool &ff_shared) {
     // per-level constants where a lane can index them by its own level
@@ -496,150 +494,94 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
     const float iz = __builtin_fminf(__builtin_fmaxf(1.0f / ray.d.z, -1e19f), 1e19f);
     const float klx = -((ray.o.x + pad) * ix), kly = -((ray.o.y + pad) * iy), klz = -((ray.o.z + pad) * iz);
     const float khx = -((ray.o.x - pad) * ix), khy = -((ray.o.y - pad) * iy), khz = -((ray.o.z - pad) * iz);
-    // spheres' leaf level
-    const float far_pad = S * (1.0f / 1048576.0f) + reach_pad;        // a length
-    const float far_len = __builtin_sqrtf(a) * (1.0f + 1.0f / 1048576.0f);
-    const float oo_keep = (KIND == DEV_SPHERE) ? cull.oo * __uint_as_float(run.hi[0]) : 0.0f;
     const uint32_t top = run.n_levels - 1u;
-    const uint32_t base0 = run.lo[8];
     const RT_CONST_AS f4 *nodes = sc.tree_rec;
 
     for (uint32_t ts = 0; ts < run.top_steps; ++ts) {
         uint32_t L = top, st = ts;
         unsigned long long pend = 0ull;
         bool act = walking;
-        // next pending sibling, of this node or of its nearest ancestor that has one
-        auto next_pending = [&]() {
-            const unsigned long long rest = pend >> (8u * L);
-            if (rest == 0ull || h.t != h.t) {
-                act = false;
-            } else {
-                const uint32_t z = (uint32_t)__builtin_ctzll(rest);
-                const uint32_t up = z >> 3, k = z & 7u;
-                L += up;
-                st = ((st >> (3u * up)) & ~7u) | k;
-                pend &= ~(1ull << (8u * L + k));
-            }
-        };
-        // exact test of the primitives of leaf step `st` named by `bits`, in slot order
-        auto exact_tests = [&](uint32_t bits) {
-            while (bits != 0u) {
-                const uint32_t k = (uint32_t)__builtin_ctz(bits);
-                bits &= bits - 1u;
-                const uint32_t idx = 8u * st + k;
-                if (idx < run.count) {
-                    RTK_COUNT(sc, 4, 1);
-                    RTK_COUNT_ANY(sc, 7, 1);
-                    const uint32_t slot = run.first + idx;
-                    if (KIND == DEV_SPHERE) sphere_exact(sc, slot, ID_LATER, ray, a, t_min, h, ff_shared);
-                    else tri_exact(sc, slot, ID_LATER, ray, t_min, h, ff_shared);
+        while (__builtin_amdgcn_ballot_w64(act) != 0ull) {
+            RTK_COUNT(sc, 2, 1);
+            RTK_COUNT(sc, 5, __builtin_popcountll(__builtin_amdgcn_ballot_w64(act)));
+            if (act) {
+                const uint32_t at = tbl.base[L] + 12u * st;
+                f4 nd[12];
+                if (L >= lds_from_level) {
+                    const f4 *src = tree_top + (at - sc.lds_first);
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) nd[q] = src[q];
+                } else {
+                    const RT_CONST_AS f4 *src = nodes + (size_t)at;
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) nd[q] = src[q];
                 }
-            }
-        };
-        for (;;) {
-            const unsigned long long on_box = __builtin_amdgcn_ballot_w64(act && (KIND == DEV_TRI || L != 0u));
-            const unsigned long long on_ball = (KIND == DEV_TRI) ? 0ull : __builtin_amdgcn_ballot_w64(act && L == 0u);
-            if ((on_box | on_ball) == 0ull) break;
-            // a ball step as soon as half as many lanes wait for one as for a box step (measured)
-            if (__builtin_popcountll(on_box) >= 2 * __builtin_popcountll(on_ball)) {
-                // ---- box step
-                RTK_COUNT(sc, 2, 1);
-                RTK_COUNT(sc, 5, __builtin_popcountll(on_box));
-                if (act && (KIND == DEV_TRI || L != 0u)) {
-                    const uint32_t at = tbl.base[L] + 12u * st;
-                    f4 nd[12];
-                    if (L >= lds_from_level) {
-                        const f4 *src = tree_top + (at - sc.lds_first);
+                uint32_t sign_bits = 0u;
+                uint32_t nearest = 0xffffffffu;   // min over surviving children of (entry distance | index)
 #pragma unroll
-                        for (int q = 0; q < 12; ++q) nd[q] = src[q];
-                    } else {
-                        const RT_CONST_AS f4 *src = nodes + (size_t)at;
+                for (int pr = 0; pr < 4; ++pr) {
+                    const f4 X = nd[3 * pr], Y = nd[3 * pr + 1], Z = nd[3 * pr + 2];   // lo0, lo1, hi0, hi1
+                    const f2 ix2 = {ix, ix}, iy2 = {iy, iy}, iz2 = {iz, iz};
+                    const f2 tlx = __builtin_elementwise_fma(X.xy, ix2, (f2){klx, klx}), thx = __builtin_elementwise_fma(X.zw, ix2, (f2){khx, khx});
+                    const f2 tly = __builtin_elementwise_fma(Y.xy, iy2, (f2){kly, kly}), thy = __builtin_elementwise_fma(Y.zw, iy2, (f2){khy, khy});
+                    const f2 tlz = __builtin_elementwise_fma(Z.xy, iz2, (f2){klz, klz}), thz = __builtin_elementwise_fma(Z.zw, iz2, (f2){khz, khz});
+                    float tn[2], nn[2];
 #pragma unroll
-                        for (int q = 0; q < 12; ++q) nd[q] = src[q];
+                    for (int c = 0; c < 2; ++c) {
+                        const float ax_ = c ? tlx.y : tlx.x, bx_ = c ? thx.y : thx.x;
+                        const float ay_ = c ? tly.y : tly.x, by_ = c ? thy.y : thy.x;
+                        const float az_ = c ? tlz.y : tlz.x, bz_ = c ? thz.y : thz.x;
+                        const float enter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax_, bx_), __builtin_fminf(ay_, by_)),
+                                                            __builtin_fmaxf(__builtin_fminf(az_, bz_), 0.0f));
+                        const float leave = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax_, bx_), __builtin_fmaxf(ay_, by_)),
+                                                            __builtin_fminf(__builtin_fmaxf(az_, bz_), h.t));
+                        tn[c] = enter;
+                        nn[c] = leave - enter;   // >= 0: some point of the ray in front of the best hit is inside
                     }
-                    uint32_t sign_bits = 0u;
-                    uint32_t nearest = 0xffffffffu;   // min over surviving children of (entry distance | index)
-#pragma unroll
-                    for (int pr = 0; pr < 4; ++pr) {
-                        const f4 X = nd[3 * pr], Y = nd[3 * pr + 1], Z = nd[3 * pr + 2];   // lo0, lo1, hi0, hi1
-                        const f2 ix2 = {ix, ix}, iy2 = {iy, iy}, iz2 = {iz, iz};
-                        const f2 tlx = __builtin_elementwise_fma(X.xy, ix2, (f2){klx, klx}), thx = __builtin_elementwise_fma(X.zw, ix2, (f2){khx, khx});
-                        const f2 tly = __builtin_elementwise_fma(Y.xy, iy2, (f2){kly, kly}), thy = __builtin_elementwise_fma(Y.zw, iy2, (f2){khy, khy});
-                        const f2 tlz = __builtin_elementwise_fma(Z.xy, iz2, (f2){klz, klz}), thz = __builtin_elementwise_fma(Z.zw, iz2, (f2){khz, khz});
-                        float tn[2], nn[2];
-#pragma unroll
-                        for (int c = 0; c < 2; ++c) {
-                            const float ax_ = c ? tlx.y : tlx.x, bx_ = c ? thx.y : thx.x;
-                            const float ay_ = c ? tly.y : tly.x, by_ = c ? thy.y : thy.x;
-                            const float az_ = c ? tlz.y : tlz.x, bz_ = c ? thz.y : thz.x;
-                            const float enter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax_, bx_), __builtin_fminf(ay_, by_)),
-                                                                __builtin_fmaxf(__builtin_fminf(az_, bz_), 0.0f));
-                            const float leave = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax_, bx_), __builtin_fmaxf(ay_, by_)),
-                                                                __builtin_fminf(__builtin_fmaxf(az_, bz_), h.t));
-                            tn[c] = enter;
-                            nn[c] = leave - enter;   // >= 0: some point of the ray in front of the best hit is inside
-                        }
-                        // enter >= 0 orders like its bit pattern; the low three bits carry the child
-                        // index, a rejected child (negative nn) becomes all ones
-                        const uint32_t s0 = (uint32_t)((int32_t)__float_as_uint(nn[0]) >> 31);
-                        const uint32_t s1 = (uint32_t)((int32_t)__float_as_uint(nn[1]) >> 31);
-                        sign_bits |= s0 & (1u << (2 * pr));
-                        sign_bits |= s1 & (1u << (2 * pr + 1));
-                        const uint32_t kx = ((__float_as_uint(tn[0]) & ~7u) | (uint32_t)(2 * pr)) | s0;
-                        const uint32_t ky = ((__float_as_uint(tn[1]) & ~7u) | (uint32_t)(2 * pr + 1)) | s1;
-                        nearest = min(nearest, min(kx, ky));
-                    }
-                    // children past the end of the level below do not exist
-                    const uint32_t have = min(8u, tbl.count[L] - 8u * st);
-                    const uint32_t bits = ~sign_bits & ((1u << have) - 1u);
-                    if (KIND == DEV_TRI && L == 0u) {
-                        exact_tests(bits);
-                        next_pending();
-                    } else if (bits != 0u) {
-                        // descend into the surviving child the ray enters first (so that a near
-                        // hit bounds the rest of the walk early), remember the others
-                        uint32_t k = nearest & 7u;
-                        if (((bits >> k) & 1u) == 0u) k = (uint32_t)__builtin_ctz(bits);   // nearest was a masked-out child
-                        L -= 1u;
-                        pend |= (unsigned long long)(bits & ~(1u << k)) << (8u * L);
-                        st = 8u * st + k;
-                    } else {
-                        next_pending();
-                    }
+                    // enter >= 0 orders like its bit pattern; the low three bits carry the child
+                    // index, a rejected child (negative nn) becomes all ones
+                    const uint32_t s0 = (uint32_t)((int32_t)__float_as_uint(nn[0]) >> 31);
+                    const uint32_t s1 = (uint32_t)((int32_t)__float_as_uint(nn[1]) >> 31);
+                    sign_bits |= s0 & (1u << (2 * pr));
+                    sign_bits |= s1 & (1u << (2 * pr + 1));
+                    const uint32_t kx = ((__float_as_uint(tn[0]) & ~7u) | (uint32_t)(2 * pr)) | s0;
+                    const uint32_t ky = ((__float_as_uint(tn[1]) & ~7u) | (uint32_t)(2 * pr + 1)) | s1;
+                    nearest = min(nearest, min(kx, ky));
                 }
-            } else if (KIND == DEV_SPHERE) {
-                // ---- ball step
-                RTK_COUNT(sc, 3, 1);
-                RTK_COUNT(sc, 6, __builtin_popcountll(on_ball));
-                if (act && L == 0u) {
-                    const RT_CONST_AS f4 *src = nodes + (size_t)(base0 + 10u * st);
-                    f4 nd[10];
-#pragma unroll
-                    for (int q = 0; q < 10; ++q) nd[q] = src[q];
-                    const float tl = __builtin_fmaf(h.t, far_len, far_pad);   // inf while nothing is hit
-                    uint32_t sign_bits = 0u;
-#pragma unroll
-                    for (int pr = 0; pr < 4; ++pr) {
-                        const f4 A = nd[pr];          // cx0, cx1, cy0, cy1
-                        const f4 B = nd[4 + pr];      // cz0, cz1, thr0, thr1
-                        const f4 R4 = nd[8 + (pr >> 1)];
-                        const f2 rr = (pr & 1) ? R4.zw : R4.xy;   // radii of the pair
-                        const f2 ux = {cull.ux, cull.ux}, uy = {cull.uy, cull.uy}, uz = {cull.uz, cull.uz};
-                        const f2 nou = {cull.nou, cull.nou}, ax = {cull.ax, cull.ax}, ay = {cull.ay, cull.ay};
-                        const f2 az = {cull.az, cull.az}, oo = {oo_keep, oo_keep}, tl2 = {tl, tl};
-                        const f2 m = __builtin_elementwise_fma(A.xy, ux, __builtin_elementwise_fma(A.zw, uy, __builtin_elementwise_fma(B.xy, uz, nou)));
-                        const f2 w = __builtin_elementwise_fma(A.xy, ax, __builtin_elementwise_fma(A.zw, ay, __builtin_elementwise_fma(B.xy, az, oo)));
-                        f2 mp;
-                        mp.x = __builtin_fmaxf(m.x, 0.0f); mp.y = __builtin_fmaxf(m.y, 0.0f);
-                        const f2 g = __builtin_elementwise_fma(-mp, mp, w);
-                        const f2 n1 = B.zw - g;             // >= 0: the ray passes within reach sideways
-                        const f2 n2 = (tl2 + rr) - m;       // >= 0: the ball starts before the best hit
-                        const float nx = __builtin_fminf(n1.x, n2.x), ny = __builtin_fminf(n1.y, n2.y);
-                        sign_bits |= (__float_as_uint(nx) >> 31) << (2 * pr);
-                        sign_bits |= (__float_as_uint(ny) >> 31) << (2 * pr + 1);
+                // children past the end of the level below do not exist
+                const uint32_t have = min(8u, tbl.count[L] - 8u * st);
+                uint32_t bits = ~sign_bits & ((1u << have) - 1u);
+                if (L != 0u && bits != 0u) {
+                    // descend into the surviving child the ray enters first (so that a near
+                    // hit bounds the rest of the walk early), remember the others
+                    uint32_t k = nearest & 7u;
+                    if (((bits >> k) & 1u) == 0u) k = (uint32_t)__builtin_ctz(bits);   // nearest was a masked-out child
+                    L -= 1u;
+                    pend |= (unsigned long long)(bits & ~(1u << k)) << (8u * L);
+                    st = 8u * st + k;
+                } else {
+                    // level 0: the exact test of the primitives this lane could not reject, in
+                    // slot order
+                    while (bits != 0u) {
+                        const uint32_t k = (uint32_t)__builtin_ctz(bits);
+                        bits &= bits - 1u;
+                        const uint32_t slot = run.first + 8u * st + k;
+                        RTK_COUNT(sc, 4, 1);
+                        RTK_COUNT_ANY(sc, 7, 1);
+                        if (KIND == DEV_SPHERE) sphere_exact(sc, slot, ID_LATER, ray, a, t_min, h, ff_shared);
+                        else tri_exact(sc, slot, ID_LATER, ray, t_min, h, ff_shared);
                     }
-                    exact_tests(~sign_bits & 0xffu);
-                    next_pending();
+                    // next pending sibling, of this node or of its nearest ancestor that has one
+                    const unsigned long long rest = pend >> (8u * L);
+                    if (rest == 0ull || h.t != h.t) {
+                        act = false;
+                    } else {
+                        const uint32_t z = (uint32_t)__builtin_ctzll(rest);
+                        const uint32_t up = z >> 3, k = z & 7u;
+                        L += up;
+                        st = ((st >> (3u * up)) & ~7u) | k;
+                        pend &= ~(1ull << (8u * L + k));
+                    }
                 }
             }
         }
@@ -658,7 +600,7 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
 // take the run in list order, the second from the state it entered with.
 // ----------------------------------------------------------------------
 template <int KIND>
-__device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &run, const Cull &cull, bool tracing,
+__device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &run, bool tracing,
                                           TreeTable &tbl, const f4 *tree_top, uint32_t lds_from_level,
                                           const Ray &ray, float a, float t_min, Hit &h, bool &ff_shared) {
     const float big = 1e18f;
@@ -674,7 +616,7 @@ __device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &ru
             tbl.entry_slot[lane] = h.slot;
             tbl.entry_bits[lane] = (uint32_t)(h.kind + 1) | ((uint32_t)h.ff << 8) | ((uint32_t)ff_shared << 9);
         }
-        walk_tree<KIND>(sc, run, cull, walking, tbl, tree_top, lds_from_level, ray, a, t_min, h, ff_shared);
+        walk_tree<KIND>(sc, run, walking, tbl, tree_top, lds_from_level, ray, a, t_min, h, ff_shared);
         if (walking && h.id == ID_LATER) h.id = (int32_t)(KIND == DEV_SPHERE ? sc.sph_id[h.slot] : sc.tri_id[h.slot]);
         if (walking && h.t != h.t) {
             const uint32_t bits = tbl.entry_bits[lane];
@@ -716,15 +658,17 @@ __device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, f
     for (uint32_t r = 0; r < sc.n_runs; ++r) {
         const RunView run = load_run(sc, r);
         if (MODES != 0 && run.mode != RUN_EXACT) {
-            // the ball tests (spheres) need the unit direction and |o|^2; triangle trees are all boxes
-            if (!have_cull && run.kind == DEV_SPHERE) { cull = cull_setup(ray, a); have_cull = true; }
             // levels >= from are read from the LDS copy (only the cached run has any)
             const uint32_t from = (r == sc.lds_run) ? sc.lds_level : 0xffffffffu;
-            if ((MODES & 1) && run.mode == RUN_FLAT) scan_flat(sc, run, cull, tracing, ray, a, t_min, h, ff_shared);
-            else if ((MODES & 2) && run.kind == DEV_SPHERE)
-                scan_tree<DEV_SPHERE>(sc, run, cull, tracing, tbl, tree_top, from, ray, a, t_min, h, ff_shared);
-            else if (MODES & 2)
-                scan_tree<DEV_TRI>(sc, run, cull, tracing, tbl, tree_top, from, ray, a, t_min, h, ff_shared);
+            if ((MODES & 1) && run.mode == RUN_FLAT) {
+                // the ball rejection test needs the unit direction and |o|^2
+                if (!have_cull) { cull = cull_setup(ray, a); have_cull = true; }
+                scan_flat(sc, run, cull, tracing, ray, a, t_min, h, ff_shared);
+            } else if ((MODES & 2) && run.kind == DEV_SPHERE) {
+                scan_tree<DEV_SPHERE>(sc, run, tracing, tbl, tree_top, from, ray, a, t_min, h, ff_shared);
+            } else if (MODES & 2) {
+                scan_tree<DEV_TRI>(sc, run, tracing, tbl, tree_top, from, ray, a, t_min, h, ff_shared);
+            }
         } else if (run.kind == DEV_SPHERE) {
             for (uint32_t k = 0; k < run.count; ++k)
                 sphere_exact(sc, run.first + k, (int32_t)(run.id0 + k), ray, a, t_min, h, ff_shared);

@@ -162,16 +162,6 @@ void append_paired(std::vector<float4> &out, const std::vector<float4> &recs) {
     }
 }
 
-// Tree layout of one step (eight balls, 160 bytes): the x,y of the four pairs,
-// the z,thr of the four pairs, then the eight radii (rounded up) for the
-// "beyond the best hit" test.
-void append_tree_step(std::vector<float4> &out, const float4 *recs, const float *radii) {
-    for (int p = 0; p < 4; ++p) out.push_back(make_float4(recs[2 * p].x, recs[2 * p + 1].x, recs[2 * p].y, recs[2 * p + 1].y));
-    for (int p = 0; p < 4; ++p) out.push_back(make_float4(recs[2 * p].z, recs[2 * p + 1].z, recs[2 * p].w, recs[2 * p + 1].w));
-    out.push_back(make_float4(radii[0], radii[1], radii[2], radii[3]));
-    out.push_back(make_float4(radii[4], radii[5], radii[6], radii[7]));
-}
-
 // Appends one level of boxes (one per entry of `boxes`, in steps of eight, twelve float4
 // per step: per pair of boxes {lo0,lo1,hi0,hi1} for x, for y, for z), rounded outwards.
 void append_box_level(std::vector<float4> &out, const std::vector<Box> &boxes) {
@@ -192,18 +182,17 @@ void append_box_level(std::vector<float4> &out, const std::vector<Box> &boxes) {
 
 // Builds the implicit 8-ary tree over the leaves of a run (already in slot order) and
 // appends its records to scene.tree_rec.
-//   level 0   spheres (`balls` given): the spheres' own rejection records, ten float4 per
-//             step of eight, margin leaf_eps - a ball is the tight fit for a sphere;
-//             triangles (`balls` null): their gate boxes, twelve float4 per step of eight;
-//   level L>0 one axis-aligned box per step of level L-1, in steps of eight.
+//   level 0   one box per primitive (a sphere's extent, a triangle's gate box), in steps of
+//             eight, twelve float4 per step;
+//   level L>0 one box per step of level L-1, in steps of eight.
 // Boxes hold plain extents rounded outwards; the kernel widens them per ray by a pad that
 // covers what the reference's f32 arithmetic can add to a primitive's reach (for a sphere:
 // the root of a discriminant that is uncertain by kappa |o-c|^2 lies up to
-// sqrt(r^2 + kappa |o-c|^2) from the centre) plus the rounding of the slab test itself.
-// Boxes fit flat or elongated groups (spheres resting on a plane, a terrain mesh) far better
-// than balls do.  A leaf that is unbounded makes every box above it infinite.
-void build_tree(HostScene &sc, DevRun &run, const std::vector<Ball> *balls, const std::vector<Box> &leaf_boxes,
-                double leaf_eps) {
+// sqrt(r^2 + kappa |o-c|^2) from the centre; rho_min, the smallest radius of the run, bounds
+// that) plus the rounding of the slab test itself.  Boxes fit flat or elongated groups
+// (spheres resting on a plane, a terrain mesh) far better than balls do.  A leaf that is
+// unbounded makes every box above it infinite.
+void build_tree(HostScene &sc, DevRun &run, const std::vector<Box> &leaf_boxes, double rho_min) {
     for (const Box &b : leaf_boxes) {
         if (b.lo[0] == -INFINITY) continue;   // unbounded
         double far2 = 0.0;
@@ -213,33 +202,21 @@ void build_tree(HostScene &sc, DevRun &run, const std::vector<Ball> *balls, cons
         }
         run.reach = std::max(run.reach, round_up(std::sqrt(far2)));
     }
-    run.level_base[0] = (uint32_t)sc.tree_rec.size();
-    if (balls) {
-        double rho_all = INFINITY;
-        std::vector<float4> recs;
-        std::vector<float> radii;
-        for (const Ball &b : *balls) {
-            float4 rec = reject_record(b, leaf_eps);
-            if (rec.w == 0.0f) rec.w = 0.0f;   // no negative zero: the kernel reads sign bits
-            recs.push_back(rec);
-            radii.push_back(round_up(std::abs(b.r) * (1.0 + 1e-6)));
-            if (!unbounded(b)) rho_all = std::min(rho_all, std::abs(b.r));
-        }
-        run.inv_2rho = rho_all > 0 && rho_all < INFINITY ? round_up(0.5 / rho_all) : INFINITY;
-        while (recs.size() % 8) { recs.push_back(NEVER_PASS); radii.push_back(0.0f); }
-        run.level_aux[0] = float_to_bits((float)(1.0 - leaf_eps));
-        for (size_t k = 0; k < recs.size(); k += 8) append_tree_step(sc.tree_rec, &recs[k], &radii[k]);
-    } else {
-        run.level_aux[0] = (uint32_t)leaf_boxes.size();
-        append_box_level(sc.tree_rec, leaf_boxes);
-    }
-
+    run.inv_2rho = rho_min > 0 && rho_min < INFINITY ? round_up(0.5 / rho_min) : INFINITY;
     std::vector<Box> cur = leaf_boxes;
-    for (uint32_t level = 1;; ++level) {
-        // one box per step (eight records) of the level below
-        const size_t m = (cur.size() + 7) / 8;
-        std::vector<Box> up(m);
-        for (size_t k = 0; k < m; ++k) {
+    for (uint32_t level = 0;; ++level) {
+        run.level_base[level] = (uint32_t)sc.tree_rec.size();
+        run.level_aux[level] = (uint32_t)cur.size();
+        append_box_level(sc.tree_rec, cur);
+        const size_t n_steps = (cur.size() + 7) / 8;
+        if (level > 0 && (n_steps == 1 || level + 1 == DEV_MAX_LEVELS)) {
+            run.n_levels = level + 1;
+            run.top_steps = (uint32_t)n_steps;
+            return;
+        }
+        // one box per step (eight boxes) of this level
+        std::vector<Box> up(n_steps);
+        for (size_t k = 0; k < n_steps; ++k) {
             Box bx = {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
             for (size_t c = 8 * k; c < std::min(cur.size(), 8 * k + 8); ++c)
                 for (int ax = 0; ax < 3; ++ax) {
@@ -247,15 +224,6 @@ void build_tree(HostScene &sc, DevRun &run, const std::vector<Ball> *balls, cons
                     bx.hi[ax] = std::max(bx.hi[ax], cur[c].hi[ax]);
                 }
             up[k] = bx;
-        }
-        run.level_base[level] = (uint32_t)sc.tree_rec.size();
-        run.level_aux[level] = (uint32_t)m;
-        append_box_level(sc.tree_rec, up);
-        const size_t n_steps = (m + 7) / 8;
-        if (n_steps == 1 || level + 1 == DEV_MAX_LEVELS) {
-            run.n_levels = level + 1;
-            run.top_steps = (uint32_t)n_steps;
-            return;
         }
         cur.swap(up);
     }
@@ -341,12 +309,14 @@ int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::strin
             }
             if (run.mode == RUN_TREE) {
                 std::vector<Box> boxes(count);
+                double rho_min = INFINITY;
                 for (uint32_t k = 0; k < count; ++k) {
                     const Ball &b = sorted[k];
                     const double r = std::abs(b.r);
                     boxes[k] = unbounded(b) ? EVERYWHERE : Box{{b.x - r, b.y - r, b.z - r}, {b.x + r, b.y + r, b.z + r}};
+                    if (!unbounded(b)) rho_min = std::min(rho_min, r);
                 }
-                build_tree(sc, run, &sorted, boxes, LEAF_EPS_SPHERE);
+                build_tree(sc, run, boxes, rho_min);
             } else if (run.mode == RUN_FLAT) {
                 std::vector<float4> recs;
                 for (const Ball &b : sorted) recs.push_back(reject_record(b, LEAF_EPS_SPHERE));
@@ -414,7 +384,7 @@ int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::strin
                 sc.tri_id.push_back(id + order[k]);
                 sc.order[run.order_base + order[k]] = k;
             }
-            if (run.mode == RUN_TREE) build_tree(sc, run, nullptr, sorted, 0.0);
+            if (run.mode == RUN_TREE) build_tree(sc, run, sorted, INFINITY);
         }
         sc.runs.push_back(run);
         id = end;

@@ -38,6 +38,10 @@ class Oracle:
         lib.orc_trace_one.restype = C.c_int
         lib.orc_trace_one.argtypes = [C.POINTER(_lib.rt_scene), _fp, _fp, f3, f3, C.c_float, C.c_float,
                                       C.c_uint32, C.c_uint32, C.c_uint32, _fp]
+        lib.orc_path.restype = C.c_int
+        lib.orc_path.argtypes = [C.POINTER(_lib.rt_scene), C.POINTER(_lib.rt_camera), _fp, _fp, _fp,
+                                 C.POINTER(_lib.rt_params), C.c_uint32, C.c_uint32, C.c_uint32, _fp,
+                                 C.c_uint32, _fp]
         lib.orc_get_ray.restype = None
         lib.orc_get_ray.argtypes = [C.POINTER(_lib.rt_camera)] + [C.c_float] * 4 + [_fp]
         lib.orc_sky.restype = None
@@ -95,6 +99,20 @@ class Oracle:
         return {"hit": bool(out[0]), "index": int(out[1]), "t": out[2], "front_face": bool(out[3]),
                 "p": out[4:7].copy(), "normal": out[7:10].copy(), "dir": out[10:13].copy(),
                 "attenuation": out[13:16].copy()}
+
+    def path(self, flat, cam, tables, params, i, j, s):
+        """segments of the path of pixel (i, j from the bottom), sample s:
+        (array[n, 9] of {origin, direction, hit, list index, t}, colour[3])"""
+        out = np.zeros((32, 9), dtype=np.float32)
+        colour = np.zeros(3, dtype=np.float32)
+        cam_struct = cam.struct if hasattr(cam, "struct") else cam
+        n = self.lib.orc_path(C.byref(flat.struct), C.byref(cam_struct),
+                              tables["disc"].ctypes.data_as(_fp), tables["sphere"].ctypes.data_as(_fp),
+                              tables["screen"].ctypes.data_as(_fp), C.byref(params), i, j, s,
+                              out.ctypes.data_as(_fp), 32, colour.ctypes.data_as(_fp))
+        if n < 0:
+            raise RuntimeError("orc_path failed: %d" % n)
+        return out[:n].copy(), colour
 
     def get_ray(self, cam, s, t, a, b):
         out = np.zeros(6, dtype=np.float32)

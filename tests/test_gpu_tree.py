@@ -259,6 +259,45 @@ def test_far_away_camera_and_scene(renderer, oracle, tables):
     check(renderer, oracle, tables, s.flatten(), cam, [make_params(96, 64, spp=3)])
 
 
+@pytest.mark.parametrize("n_spheres", [40, 200])
+def test_rays_with_extreme_origins_and_directions(renderer, oracle, tables, n_spheres):
+    """origins from 1e17 to 1e30 (|o|^2 overflows f32 from 1.8e19 on) and directions of length 1e-25
+    to 1e20: Sphere::hit then works with infinities and accepts NaN roots
+    (src/geometry/mod.rs:62-79), so no conservative test may reject anything for such rays - in the
+    rejection scan of 32-63 spheres, in the list-order scan of longer runs, and in the tree"""
+    rng = np.random.default_rng(14)
+    s = HittableList()
+    for _ in range(n_spheres):
+        s.add(Sphere(tuple(rng.uniform(-3, 3, 3)), float(rng.uniform(0.2, 0.7)), _mat(rng)))
+    flat = s.flatten()
+    p = [make_params(48, 32, spp=2)]
+    cases = [((0.0, 0.0, 1e17), 1.0), ((0.0, 0.0, 1e19), 1.0), ((3e19, -2e19, 1e19), 1.0), ((5e21, 2e20, -3e21), 1.0),
+             ((0.0, 1e30, 0.0), 1.0), ((0.0, 0.0, 8.0), 1e7), ((0.0, 0.0, 8.0), 1e20), ((0.0, 0.0, 8.0), 1e-8),
+             ((0.0, 0.0, 8.0), 1e-25), ((1e10, 0.0, 1e10), 1e15)]
+    for origin, scale in cases:
+        o = np.array(origin, dtype=np.float64)
+        w = -o / np.linalg.norm(o)                        # looks at the world origin
+        u = np.cross((0.0, 1.0, 0.0), w) if abs(w[1]) < 0.9 else np.cross((1.0, 0.0, 0.0), w)
+        u /= np.linalg.norm(u)
+        v = np.cross(w, u)
+        cam = _lib.rt_camera()
+        cam.origin[:] = tuple(o)
+        hor, ver = 0.6 * scale * u, 0.4 * scale * v
+        cam.lower_left_corner[:] = tuple(o - hor / 2 - ver / 2 + scale * w)
+        cam.horizontal[:] = tuple(hor)
+        cam.vertical[:] = tuple(ver)
+        cam.u[:] = tuple(u)
+        cam.v[:] = tuple(v)
+        cam.lens_radius = 0.0
+        orc = render_oracle(oracle, tables, flat, cam, p)
+        _same_with_nans(render_gpu(renderer, flat, cam, p), orc, oracle)
+        os.environ["RT_HIP_FLAT_SCAN"] = "1"
+        try:
+            _same_with_nans(render_gpu(renderer, flat, cam, p), orc, oracle)
+        finally:
+            del os.environ["RT_HIP_FLAT_SCAN"]
+
+
 def test_list_order_scan_equals_tree_on_the_gpu(renderer):
     """RT_HIP_FLAT_SCAN=1 uploads the same scene without a tree (every sphere tested in list
     order); sums, ids and segment counts must be bit-identical at a size the oracle cannot reach"""

@@ -476,6 +476,31 @@ def test_band_partition_covers_frame_once(oracle, tables):
     assert np.array_equal(acc.view(np.uint32), full.view(np.uint32)) and seg == seg_full
 
 
+def test_path_log_adds_up_to_the_render(oracle, tables):
+    """the per-path log used to diagnose differences: the colours of a pixel's paths, added in
+    sample order, are the pixel's sum; the segments add up; each segment starts where the one
+    before hit (origin + t * direction, src/geometry/mod.rs:32)"""
+    flat = Scene.get_scene().flatten(); cam = oracle.scene_camera(0, 0.1)
+    p = make_params(W0, H0, spp=3, seed=4)
+    acc, ids, seg = oracle.render(flat, cam, tables, p)
+    total = 0
+    for j in range(H0):
+        for i in range(W0):
+            colour = np.zeros(3, dtype=f32)
+            for s in range(3):
+                segs, c = oracle.path(flat, cam, tables, p, i, j, s)
+                total += len(segs)
+                colour = colour + c
+                assert 1 <= len(segs) <= 10
+                assert all(e[6] == 1 for e in segs[:-1])
+                if s == 0:
+                    assert (int(segs[0][7]) if segs[0][6] else -1) == ids[H0 - 1 - j, i]
+                for e, nxt in zip(segs[:-1], segs[1:]):
+                    assert np.array_equal(nxt[0:3], e[0:3] + e[8] * e[3:6])
+            assert np.array_equal(colour.view(np.uint32), acc[H0 - 1 - j, i, :3].view(np.uint32))
+    assert total == seg
+
+
 def test_depth_budget(oracle, tables):
     """ray_colour depth counts scene.hit calls (src/raytracer.rs:69,75): with a
     budget of 1 every pixel that hits anything is black, sky pixels keep colour"""
