@@ -42,6 +42,9 @@ struct Ctx {
     float4 *d_samples = nullptr;   // sample_chunk colour planes, see DevFrame::samples
     uint32_t sample_chunk = 0;     // samples per pixel one launch renders at most
     unsigned long long *d_segments = nullptr;
+    uint32_t *d_queue = nullptr;       // two counters used by alternate launches, see DevFrame::queue
+    uint32_t launches = 0;             // render launches so far (picks the counter)
+    uint32_t n_cus = 0;                // compute units of the device
     bool have_frame = false;
 };
 
@@ -126,6 +129,11 @@ int rt_create(int device, rt_ctx **out) {
     if ((e = hipMalloc(reinterpret_cast<void **>(&c->d_screen), 16384 * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc(reinterpret_cast<void **>(&c->d_segments), 8 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMemset(c->d_segments, 0, 8 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset");
+    if ((e = hipMalloc(reinterpret_cast<void **>(&c->d_queue), 64)) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMemset(c->d_queue, 0, 64)) != hipSuccess) return bail(e, "hipMemset");
+    int cus = 0;
+    if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return bail(e, "hipDeviceGetAttribute");
+    c->n_cus = cus > 0 ? (uint32_t)cus : 1u;
     *out = reinterpret_cast<rt_ctx *>(c);
     return RT_OK;
 }
@@ -141,6 +149,7 @@ void rt_destroy(rt_ctx *ctx) {
     if (c->d_sphere) (void)hipFree(c->d_sphere);
     if (c->d_screen) (void)hipFree(c->d_screen);
     if (c->d_segments) (void)hipFree(c->d_segments);
+    if (c->d_queue) (void)hipFree(c->d_queue);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -262,16 +271,24 @@ int rt_render(rt_ctx *ctx, const rt_params *p) {
     if (!(p->t_min == p->t_min)) return fail(c, RT_E_BADARG, "rt_render: t_min is NaN");
     const uint32_t n_bands = bands_of(p->height, p->band_begin, p->band_stride);
     if (n_bands == 0 || p->sample_count == 0) return RT_OK;
-    if (n_bands > 65535u) return fail(c, RT_E_BADARG, "rt_render: too many bands for one launch");
     HIP_TRY(c, hipSetDevice(c->device));
-    DevFrame fr{c->d_disc, c->d_sphere, c->d_screen, c->d_accum, c->d_ids, c->d_samples, c->d_segments};
+    DevFrame fr{c->d_disc, c->d_sphere, c->d_screen, c->d_accum, c->d_ids, c->d_samples, c->d_segments,
+                nullptr, nullptr};
     // one launch per sample_chunk samples: the per-sample colours of a launch are staged
     // in d_samples before they are added to the sums in sample order
     rt_params part = *p;
+    // development aid: RT_HIP_UNIT_ROWS=8|4|2|1 fixes the rows of a tile per work unit
+    // (default: by launch size, see rtk_launch_render)
+    const char *ur = std::getenv("RT_HIP_UNIT_ROWS");
+    const int rows = ur ? std::atoi(ur) : 0;
+    const int unit_rows_log2 = rows == 8 ? 3 : rows == 4 ? 2 : rows == 2 ? 1 : rows == 1 ? 0 : -1;
     for (uint32_t done = 0; done < p->sample_count; done += c->sample_chunk) {
         part.sample_begin = p->sample_begin + done;
         part.sample_count = std::min(c->sample_chunk, p->sample_count - done);
-        HIP_TRY(c, rtk_launch_render(c->dsc, c->cam, part, fr, n_bands, c->stream));
+        fr.queue = c->d_queue + (c->launches & 1u);
+        fr.queue_next = c->d_queue + ((c->launches + 1u) & 1u);
+        HIP_TRY(c, rtk_launch_render(c->dsc, c->cam, part, fr, n_bands, c->n_cus, unit_rows_log2, c->stream));
+        c->launches += 1u;     // only a launch that ran has zeroed the other counter
     }
     return RT_OK;
 }

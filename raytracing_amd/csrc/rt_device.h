@@ -71,7 +71,7 @@ struct DevScene {
 #define DEV_SAMPLE_CHUNK 64u     // samples per pixel one launch renders at most (sizes DevFrame::samples)
 #define DEV_SAMPLE_BYTES (12ull << 30)   // ... as long as the staging planes stay under 12 GiB
 #ifndef DEV_TREE_LDS_F4
-#define DEV_TREE_LDS_F4 2296u     // float4s of tree per workgroup (36 KB): the workgroup's LDS stays under 80 KB
+#define DEV_TREE_LDS_F4 2256u     // float4s of tree per workgroup (35 KB): the workgroup's LDS stays under 80 KB
 #endif
 
 // Per-frame buffers and the lookup tables
@@ -83,10 +83,13 @@ struct DevFrame {
     int32_t *primary_ids;     // per pixel, display order
     float4 *samples;          // colour of sample k of this launch at [k * width*height + pixel]
     unsigned long long *segments;
+    uint32_t *queue;          // work units of the running launch handed out so far (zero when it starts)
+    uint32_t *queue_next;     // the counter the next launch on the stream will use: the running one zeroes it
 };
 
 hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_params &p,
-                             const DevFrame &fr, uint32_t n_bands, hipStream_t stream);
+                             const DevFrame &fr, uint32_t n_bands, uint32_t n_cus, int unit_rows_log2,
+                             hipStream_t stream);
 hipError_t rtk_launch_pack_bands(const float4 *accum, uint32_t *out, uint32_t W, uint32_t H,
                                  uint32_t band_begin, uint32_t band_stride, uint32_t n_bands,
                                  hipStream_t stream);

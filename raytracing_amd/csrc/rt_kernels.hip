@@ -1,10 +1,12 @@
 // rt_kernels.hip - the render loop as gfx950 (CDNA4, wave64) kernels.
 //
-// A workgroup renders a strip of 8x8 pixel tiles of one 8-row band.  Its work items are
-// (pixel, sample) pairs handed out through one LDS counter: as soon as a lane's path ends
-// (sky or depth budget) it takes the next item, whatever pixel that belongs to, so waves stay
-// full until the strip runs out of items; the per-sample colours are staged in memory and
-// added to each pixel's sum in sample order at the end.
+// The launch fills the chip once with resident workgroups; every wavefront takes work units
+// (a few rows of an 8x8 pixel tile x the samples of the launch) from one global queue.  Its
+// work items are (pixel, sample) pairs: as soon as a lane's path ends (sky or depth budget) it
+// takes the next item, whatever pixel that belongs to, and the wave starts its next unit while
+// the longer paths of the last one are still on the way, so waves stay full until the queue is
+// empty; the per-sample colours are staged in memory and added to each pixel's sum in sample
+// order when the pixel's unit is complete.
 // The closest-hit scan follows the primitive list in the reference's insertion order, run by
 // run (maximal stretches of one primitive kind).  Short runs: a wave-uniform loop, primitive
 // data read through scalar loads, every lane tests the same primitive against its own ray - no
@@ -19,6 +21,8 @@
 // Reference lines each device function follows are cited at the function.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <algorithm>
 
 #include "rt_device.h"
 
@@ -148,6 +152,10 @@ struct TreeTable {
     uint32_t entry_bits[64];   // kind + 1 | ff << 8 | ff_shared << 9
 };
 
+// The work units a wave has in flight (see render_tiles): column | row << 16 of the unit's first
+// pixel (row counted from the bottom), and the number of items not finished yet (0 = slot free).
+struct UnitRing { uint32_t xy[4], left[4]; };
+
 // MODES: bit 0 = the scene has RUN_FLAT runs, bit 1 = it has RUN_TREE runs; the
 // kernel is compiled once per combination so that scenes without a tree do not
 // pay registers and LDS for it
@@ -157,7 +165,7 @@ struct Lds {
     float sphere[768];                                  // src/denoising/mod.rs:59
     uint32_t mat_stack[waves_of(MODES)][RT_MAX_BOUNCES][64];
     TreeTable tree[waves_of(MODES)];                    // per-level constants of the run being walked
-    uint32_t next_item;                                 // work items handed out so far
+    UnitRing ring[waves_of(MODES)];                     // the units each wave has in flight
     f4 tree_top[(MODES & 2) ? DEV_TREE_LDS_F4 : 1];     // top levels of one tree (DevScene::lds_*)
 };
 
@@ -816,9 +824,23 @@ __device__ __forceinline__ V3 sky(V3 ud, bool gamma) {
 
 // ----------------------------------------------------------------------
 // calculate_some_pxls + ray_colour, src/raytracer.rs:232-271 and :68-92.
-// grid.x = ceil(W / (8 * waves per workgroup)): the workgroup's 8x8 tiles lie side by side,
-// grid.y = number of 8-row bands this call renders.
+//
+// The launch is a fixed number of resident workgroups; every wavefront on its own takes work
+// units from one global queue until the queue is empty.  A unit is 8, 4, 2 or 1 rows of an 8x8
+// tile (chosen per launch, see rtk_launch_render) x all samples of the launch; its work items
+// (pixel, sample), sample-major, are handed to the wave's lanes one at a time: a lane whose
+// path ends takes the next item, whatever pixel it belongs to, and when a unit runs out of
+// items the wave starts the next unit at once while its longer paths are still on the way (up
+// to four units in flight per wave, UnitRing).  Pixels differ a lot in segments per sample;
+// with one lane per pixel a wave would wait for its slowest pixel.
+//
+// The colour of every sample goes to fr.samples.  When the last item of a unit is finished
+// the wave adds the unit's samples to the pixel sums IN SAMPLE ORDER: `px_colour += ...`
+// (src/raytracer.rs:262) is an ordered f32 sum and must not depend on which lane finished
+// first.  Nothing is shared between waves.
 // ----------------------------------------------------------------------
+constexpr uint32_t ITEM_BITS = 12;   // item index inside a unit: at most 64 pixels x 64 samples
+
 template <int MODES>
 #ifndef RTK_OCC
 #define RTK_OCC 4
@@ -828,89 +850,146 @@ template <int MODES>
 // waves per SIMD without spills (one 12-wave workgroup per CU) -2 %, two waves -24 %, 4-wave
 // workgroups with a 16 KB tree copy -5 %, 96 VGPRs for five waves per SIMD -40 %.
 __global__ __launch_bounds__(waves_of(MODES) * 64, RTK_OCC)
-void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
+void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_t n_bands, uint32_t unit_rows_log2) {
     __shared__ Lds<MODES> lds;
     const SceneView sc = view_of(dsc, fr.segments);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (uint32_t k = threadIdx.x; k < 128; k += blockDim.x) lds.disc[k] = fr.tbl_disc[k];
     for (uint32_t k = threadIdx.x; k < 768; k += blockDim.x) lds.sphere[k] = fr.tbl_sphere[k];
-    if (threadIdx.x == 0) lds.next_item = 0u;
+    if (lane < 4u) lds.ring[wave].left[lane] = 0u;
+    if (blockIdx.x == 0u && threadIdx.x == 0u) *fr.queue_next = 0u;     // the next launch starts at zero
     if (MODES & 2) {
         const RT_CONST_AS f4 *src = sc.tree_rec + (size_t)dsc.lds_first;
         for (uint32_t k = threadIdx.x; k < dsc.lds_count; k += blockDim.x) lds.tree_top[k] = src[k];
     }
     __syncthreads();
 
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t W = p.width, H = p.height;
-    const uint32_t band = p.band_begin + blockIdx.y * p.band_stride;
-    const uint32_t x0 = blockIdx.x * waves_of(MODES) * TILE, y0 = band * TILE;   // the workgroup's strip of tiles
     const bool gamma = p.gamma != 0;
     const size_t n_px = (size_t)W * H;
+    UnitRing &ring = lds.ring[wave];
 
-    // Work items: (pixel of the strip, sample), sample-major, handed out through one counter
-    // per workgroup, so a lane whose path ends takes the next item whatever pixel it belongs
-    // to.  Pixels differ a lot in segments per sample; with one lane per pixel the wave would
-    // wait for its slowest pixel.  The colour of every sample goes to fr.samples and is added
-    // to the pixel's sum in sample order at the end (the sums must not depend on which lane
-    // finished first: `px_colour += ...`, src/raytracer.rs:262, is an ordered f32 sum).
-    const uint32_t strip_px = waves_of(MODES) * 64u;
-    const uint32_t n_items = strip_px * p.sample_count;
+    // units of this launch: tile by tile along the band, the row groups of a tile one after the other
+    const uint32_t tiles_x = (W + TILE - 1u) / TILE;
+    const uint32_t unit_rows = 1u << unit_rows_log2, unit_px_log2 = 3u + unit_rows_log2;
+    const uint32_t sub_log2 = 3u - unit_rows_log2;               // units per tile, log2
+    const uint32_t n_units = (tiles_x * n_bands) << sub_log2;
 
     // Per-lane state that lives across the scan is kept small (registers are what limits the
     // kernel): the work item, the ray, the depth budget and the unit-sphere counter.  Pixel,
     // sample, screen-space noise value and the path's hash key are derived from the item
     // again where they are needed.
-    uint32_t item = 0;        // this lane's work item: pixel of the strip + strip_px * (sample - sample_begin)
+    uint32_t item = 0;        // ring slot << ITEM_BITS | pixel of the unit + pixels of a unit * (sample - sample_begin)
     bool alive = false;
     Ray ray;
     ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1);
     uint32_t depth_left = p.max_bounces, path_counter = 0;
     uint32_t n_seg = 0;
-    auto column_of = [&](uint32_t it) { const uint32_t q = it % strip_px; return x0 + (q >> 6) * TILE + (q & 7u); };
-    auto row_of = [&](uint32_t it) { const uint32_t q = it % strip_px; return y0 + ((q >> 3) & 7u); };   // from the bottom
-    auto sample_of = [&](uint32_t it) { return p.sample_begin + it / strip_px; };
-    auto path_key_of = [&](uint32_t it) {
-        return mix32((row_of(it) * W + column_of(it)) ^ mix32(sample_of(it) ^ (p.seed * GOLDEN32)));
-    };
+    // wave-uniform: the unit items are being handed out from
+    uint32_t cur_slot = 3u, cur_next = 0u, cur_n = 0u;
+    bool queue_empty = false;
+    // the queue is read one unit ahead, so that the answer is there when it is needed
+    uint32_t unit_ahead = 0u;
+    if (lane == 0u) unit_ahead = atomicAdd(fr.queue, 1u);
 
-    auto start_sample = [&]() {
-        const uint32_t i = column_of(item), j = row_of(item), s = sample_of(item);
+    struct Where { uint32_t i, j, s; };      // column, row from the bottom, sample
+    auto where = [&](uint32_t it) {
+        const uint32_t slot = it >> ITEM_BITS, q = it & ((1u << ITEM_BITS) - 1u);
+        const uint32_t xy = ring.xy[slot];
+        Where w;
+        w.i = (xy & 0xffffu) + (q & 7u);
+        w.j = (xy >> 16) + ((q >> 3) & (unit_rows - 1u));
+        w.s = p.sample_begin + (q >> unit_px_log2);
+        return w;
+    };
+    auto path_key_at = [&](const Where &w) { return mix32((w.j * W + w.i) ^ mix32(w.s ^ (p.seed * GOLDEN32))); };
+
+    auto start_sample = [&](const Where &w) {
         // two disc draws per sample: jitter then lens (src/raytracer.rs:254,258);
         // sample n of a single-thread run uses entries 2n+1 and 2n+2 of the
         // pre-incremented counter (src/denoising/mod.rs:13-17)
-        const uint32_t pix = j * W + i;
-        uint32_t n = pix * p.spp + s;   // only n mod 32 matters, wrap is harmless
+        const uint32_t pix = w.j * W + w.i;
+        uint32_t n = pix * p.spp + w.s;   // only n mod 32 matters, wrap is harmless
         uint32_t k1 = (2u * n + 1u) & 63u, k2 = (2u * n + 2u) & 63u;
         float ox = lds.disc[2 * k1], oy = lds.disc[2 * k1 + 1];
         float la = lds.disc[2 * k2], lb = lds.disc[2 * k2 + 1];
-        float u = ((float)i + ox) / (float)(W - 1u);
-        float v = ((float)j + oy) / (float)(H - 1u);
+        float u = ((float)w.i + ox) / (float)(W - 1u);
+        float v = ((float)w.j + oy) / (float)(H - 1u);
         ray = get_ray(cam, u, v, la, lb);
-        path_counter = path_key_of(item);
+        path_counter = path_key_at(w);
         depth_left = p.max_bounces;
     };
-    // lanes with `need` take the next items; lanes left without one stay idle for good
+
+    // All items of the unit in `slot` are finished and their colours stored (by lanes of
+    // this wave): its pixels are added up, one pixel per lane.
+    auto finish_unit = [&](uint32_t slot) {
+        const uint32_t xy = ring.xy[slot];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t pi = (xy & 0xffffu) + (lane & 7u), pj = (xy >> 16) + (lane >> 3);
+        if ((lane >> 3) < unit_rows && pi < W && pj < H) {
+            const size_t pix_out = (size_t)(H - 1u - pj) * W + pi;   // src/raytracer.rs:265
+            float4 acc = fr.accum[pix_out];
+            V3 px = mk(acc.x, acc.y, acc.z);
+            // with a depth budget of 0 every sample is black and nothing was traced
+            const uint32_t n_add = p.max_bounces > 0 ? p.sample_count : 0u;
+            const float4 *src = fr.samples + pix_out;
+            uint32_t k = 0;
+            // eight loads on the way at a time; the additions keep their order (src/raytracer.rs:262)
+            for (; k + 8u <= n_add; k += 8u) {
+                float4 c[8];
+#pragma unroll
+                for (uint32_t m = 0; m < 8u; ++m) c[m] = src[(size_t)(k + m) * n_px];
+#pragma unroll
+                for (uint32_t m = 0; m < 8u; ++m) px = px + mk(c[m].x, c[m].y, c[m].z);
+            }
+            for (; k < n_add; ++k) {
+                const float4 c = src[(size_t)k * n_px];
+                px = px + mk(c.x, c.y, c.z);
+            }
+            fr.accum[pix_out] = make_float4(px.x, px.y, px.z, acc.w + (float)p.sample_count);
+        }
+    };
+
+    // lanes with `need` take the next items; when the current unit has none left the wave
+    // takes the next unit from the queue.  Lanes left without an item try again after the
+    // next segment (a ring slot may still be held by a unit with paths on the way).
     auto fetch = [&](bool need) {
         for (;;) {
             const unsigned long long mask = __builtin_amdgcn_ballot_w64(need);
             if (mask == 0ull) break;
-            const uint32_t cnt = (uint32_t)__builtin_popcountll(mask);
-            uint32_t base = 0;
-            if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(&lds.next_item, cnt);
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(mask));
-            if (base >= n_items) break;
+            if (cur_next >= cur_n) {
+                if (queue_empty) break;
+                const uint32_t slot = (cur_slot + 1u) & 3u;
+                if (ring.left[slot] != 0u) break;
+                const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit_ahead);
+                if (u >= n_units) { queue_empty = true; break; }
+                if (lane == 0u) unit_ahead = atomicAdd(fr.queue, 1u);
+                const uint32_t t = u >> sub_log2, sub = u & ((1u << sub_log2) - 1u);
+                const uint32_t by = t / tiles_x, tx = t - by * tiles_x;
+                const uint32_t band = p.band_begin + by * p.band_stride;
+                const uint32_t x0 = tx * TILE, y0 = band * TILE + sub * unit_rows;
+                const uint32_t vw = W - x0 < (uint32_t)TILE ? W - x0 : (uint32_t)TILE;
+                const uint32_t vh = y0 >= H ? 0u : (H - y0 < unit_rows ? H - y0 : unit_rows);
+                const uint32_t left = p.max_bounces > 0u ? vw * vh * p.sample_count : 0u;
+                if (lane == 0u) { ring.xy[slot] = x0 | (y0 << 16); ring.left[slot] = left; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                cur_slot = slot; cur_next = 0u; cur_n = p.max_bounces > 0u ? p.sample_count << unit_px_log2 : 0u;
+                if (left == 0u) { finish_unit(slot); continue; }
+            }
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            const uint32_t k = base + rank;
-            if (need && k < n_items) {
-                item = k;
-                if (column_of(k) < W && row_of(k) < H) { start_sample(); need = false; alive = true; }
+            const uint32_t k = cur_next + rank;
+            cur_next += (uint32_t)__builtin_popcountll(mask);
+            if (need && k < cur_n) {
+                const uint32_t it = (cur_slot << ITEM_BITS) | k;
+                const Where w = where(it);
+                if (w.i < W && w.j < H) { item = it; start_sample(w); need = false; alive = true; }
             }
         }
     };
 #ifdef RTK_TIMES
     unsigned long long tm_scan = 0, tm_rest = 0, tm_done = 0, tm_fetch = 0;
 #endif
-    if (p.max_bounces > 0) fetch(true);
+    fetch(true);
 
     while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
         Hit h;
@@ -925,19 +1004,22 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
         n_seg += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(alive));
         bool done = false;
         if (alive) {
-            const uint32_t i = column_of(item), j = row_of(item), s = sample_of(item);
+            const Where at = where(item);
             const uint32_t n_stack = p.max_bounces - depth_left;   // hits of this path so far
-            const size_t pix_out = (size_t)(H - 1u - j) * W + i;   // src/raytracer.rs:265
+            const size_t pix_out = (size_t)(H - 1u - at.j) * W + at.i;   // src/raytracer.rs:265
             // BlueNoise::get_screenspace, src/denoising/mod.rs:19-23: fixed per pixel
-            const float sp_bn = fr.tbl_screen[128u * (i % 128u) + (j % 128u)];
-            if (s == 0u && n_stack == 0u) fr.primary_ids[pix_out] = h.id;
+            const float sp_bn = fr.tbl_screen[128u * (at.i % 128u) + (at.j % 128u)];
+            if (at.s == 0u && n_stack == 0u) fr.primary_ids[pix_out] = h.id;
             // unit_vector(direction): the sky (src/raytracer.rs:82), Metal and Dielectric all start
             // from it; computed once for the wave instead of once per branch
             const V3 ud = unit(ray.d);
             V3 c;
             uint32_t n_hits = n_stack;
+#ifdef RTK_TIMES
+            const unsigned long long tm2 = __builtin_readcyclecounter();
+#endif
             if (h.kind >= 0) {
-                uint32_t mat = shade_hit(sc, lds.sphere, ray, ud, h, sp_bn, path_counter, path_key_of(item), n_stack);
+                uint32_t mat = shade_hit(sc, lds.sphere, ray, ud, h, sp_bn, path_counter, path_key_at(at), n_stack);
                 lds.mat_stack[wave][n_stack][lane] = mat;
                 n_hits = n_stack + 1u;
                 depth_left -= 1;
@@ -963,7 +1045,7 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
                     if (k >= 4u) c = mk(a3.x, a3.y, a3.z) * c;
                     k = k >= 4u ? k - 4u : 0u;
                 }
-                fr.samples[(size_t)(s - p.sample_begin) * n_px + pix_out] = make_float4(c.x, c.y, c.z, 0.0f);
+                fr.samples[(size_t)(at.s - p.sample_begin) * n_px + pix_out] = make_float4(c.x, c.y, c.z, 0.0f);
                 alive = false;
             }
 #ifdef RTK_TIMES
@@ -973,7 +1055,18 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
 #ifdef RTK_TIMES
         const unsigned long long tm3 = __builtin_readcyclecounter();
 #endif
-        if (__builtin_amdgcn_ballot_w64(done) != 0ull) fetch(done);
+        // count the finished items against their units (at most four different ones in a wave)
+        unsigned long long dm = __builtin_amdgcn_ballot_w64(done);
+        while (dm != 0ull) {
+            const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)(item >> ITEM_BITS), __builtin_ctzll(dm));
+            const unsigned long long same = __builtin_amdgcn_ballot_w64(done && (item >> ITEM_BITS) == slot);
+            dm &= ~same;
+            const uint32_t left = ring.left[slot] - (uint32_t)__builtin_popcountll(same);
+            if (lane == 0u) ring.left[slot] = left;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (left == 0u) finish_unit(slot);
+        }
+        if (__builtin_amdgcn_ballot_w64(!alive) != 0ull) fetch(!alive);
 #ifdef RTK_TIMES
         tm_fetch += __builtin_readcyclecounter() - tm3;
         tm_rest += __builtin_readcyclecounter() - tm1;
@@ -986,25 +1079,6 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr) {
         atomicAdd(fr.segments + 5, tm_done); atomicAdd(fr.segments + 6, tm_fetch);
     }
 #endif
-
-    // every sample of the strip is in memory once all waves are here; each thread then adds
-    // up its own pixel in sample order
-    __threadfence();
-    __syncthreads();
-    {
-        const uint32_t pi = x0 + wave * TILE + (lane & 7u), pj = y0 + (lane >> 3);
-        if (pi < W && pj < H) {
-            const size_t pix_out = (size_t)(H - 1u - pj) * W + pi;
-            float4 acc = fr.accum[pix_out];
-            V3 px = mk(acc.x, acc.y, acc.z);
-            // with a depth budget of 0 every sample is black and nothing was traced
-            for (uint32_t k = 0; k < (p.max_bounces > 0 ? p.sample_count : 0u); ++k) {
-                const float4 c = fr.samples[(size_t)k * n_px + pix_out];
-                px = px + mk(c.x, c.y, c.z);   // src/raytracer.rs:262
-            }
-            fr.accum[pix_out] = make_float4(px.x, px.y, px.z, acc.w + (float)p.sample_count);
-        }
-    }
     if (lane == 0 && n_seg != 0) atomicAdd(fr.segments, (unsigned long long)n_seg);
 }
 
@@ -1058,15 +1132,32 @@ hipError_t rtk_launch_pack_bands(const float4 *accum, uint32_t *out, uint32_t W,
     return hipGetLastError();
 }
 hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_params &p,
-                             const DevFrame &fr, uint32_t n_bands, hipStream_t stream) {
+                             const DevFrame &fr, uint32_t n_bands, uint32_t n_cus, int unit_rows_log2,
+                             hipStream_t stream) {
     const uint32_t waves = (uint32_t)rtk::waves_of((int)(sc.modes & 3u));
-    const uint32_t tile_w = waves * rtk::TILE;
-    dim3 grid((p.width + tile_w - 1u) / tile_w, n_bands, 1), block(waves * 64, 1, 1);
+    const uint32_t tiles_x = (p.width + rtk::TILE - 1u) / rtk::TILE;
+    const uint64_t n_tiles = (uint64_t)tiles_x * n_bands;
+    const uint64_t resident = (uint64_t)n_cus * (4u * RTK_OCC / waves);   // workgroups the chip holds at once
+    if (p.sample_count > 64u || p.width > 65536u || p.height > 65536u) return hipErrorInvalidValue;
+    // Rows of a tile per work unit: the fewest that still give a unit 512 work items (eight per
+    // lane).  Measured on 4K frames at 64 samples per launch, whole frame / one eighth of the
+    // bands: 1 row 133.0 / 17.8 ms, 2 rows 132.8 / 19.1, 4 rows 135.3 / 21.9, 8 rows 139.1 / 26.5
+    // (10,000 spheres); the million-triangle scene 66.7 / 9.6 ms with 1 row, 75.9 / 22.1 with 8.
+    if (unit_rows_log2 < 0 || unit_rows_log2 > 3) {
+        unit_rows_log2 = 0;
+        while (unit_rows_log2 < 3 && ((uint64_t)p.sample_count << (3 + unit_rows_log2)) < 512u) ++unit_rows_log2;
+    }
+    const uint64_t n_units = n_tiles << (3 - unit_rows_log2);
+    if (n_units >= 0xffffffffull - resident * waves) return hipErrorInvalidValue;
+    // as many workgroups as the chip holds, fewer when there are not that many work units
+    const uint64_t groups = std::max<uint64_t>(1u, std::min<uint64_t>(resident, (n_units + waves - 1u) / waves));
+    dim3 grid((uint32_t)groups, 1, 1), block(waves * 64, 1, 1);
+    const uint32_t r = (uint32_t)unit_rows_log2;
     switch (sc.modes & 3u) {
-    case 0: hipLaunchKernelGGL(rtk::render_tiles<0>, grid, block, 0, stream, sc, cam, p, fr); break;
-    case 1: hipLaunchKernelGGL(rtk::render_tiles<1>, grid, block, 0, stream, sc, cam, p, fr); break;
-    case 2: hipLaunchKernelGGL(rtk::render_tiles<2>, grid, block, 0, stream, sc, cam, p, fr); break;
-    default: hipLaunchKernelGGL(rtk::render_tiles<3>, grid, block, 0, stream, sc, cam, p, fr); break;
+    case 0: hipLaunchKernelGGL(rtk::render_tiles<0>, grid, block, 0, stream, sc, cam, p, fr, n_bands, r); break;
+    case 1: hipLaunchKernelGGL(rtk::render_tiles<1>, grid, block, 0, stream, sc, cam, p, fr, n_bands, r); break;
+    case 2: hipLaunchKernelGGL(rtk::render_tiles<2>, grid, block, 0, stream, sc, cam, p, fr, n_bands, r); break;
+    default: hipLaunchKernelGGL(rtk::render_tiles<3>, grid, block, 0, stream, sc, cam, p, fr, n_bands, r); break;
     }
     return hipGetLastError();
 }
