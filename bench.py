@@ -97,21 +97,23 @@ def flat_scan_probe(r, wl, flops_seg):
             "sample": "8 spp of the full frame, %d segments" % seg}
 
 
-def valu_from_profile(workload, kernel_ms):
-    """VALU instructions per launch of render_tiles from the committed rocprofv3 --pmc pass
-    (profiles/sq_counters.json, tools/collect_sq.py) and what fraction of the SIMDs' issue
-    cycles they fill at the measured cost of 4.2 cycles per wave instruction; None if absent."""
+def valu_from_profile(workload, segments_per_launch):
+    """VALU figures of render_tiles from the committed rocprofv3 --pmc pass (profiles/sq_counters.json,
+    tools/collect_sq.py): wave instructions per launch and per segment, and rocprof's VALUBusy formula
+    SQ_ACTIVE_INST_VALU * 4 / (SIMDs * busy cycles) with the busy cycles of the same pass
+    (SQ_BUSY_CYCLES is summed over the 32 shader engines, 1024 SIMDs: ACTIVE / (8 * BUSY)); None if absent."""
     path = os.path.join(ROOT, "profiles", "sq_counters.json")
     try:
         with open(path) as f:
             rec = json.load(f).get(workload)
-        insts = rec["per_launch"]["SQ_INSTS_VALU"]
+        pl = rec["per_launch"]
+        insts, active, busy = pl["SQ_INSTS_VALU"], pl["SQ_ACTIVE_INST_VALU"], pl["SQ_BUSY_CYCLES"]
     except (OSError, ValueError, KeyError, TypeError):
         return None
-    simd_cycles = 1024 * 2.4e9 * kernel_ms * 1e-3
     return {"wave_insts_per_launch": int(insts), "spp_per_launch": rec.get("spp_per_launch"),
-            "issue_frac_at_4.2_cycles": round(insts * 4.2 / simd_cycles, 3) if rec.get("spp_per_launch") else None,
-            "source": "profiles/sq_counters.json (rocprofv3 --pmc SQ_INSTS_VALU ...)"}
+            "wave_insts_per_wave_segment": round(insts * 64.0 / segments_per_launch, 1),
+            "valu_busy": round(active / (8.0 * busy), 3),
+            "source": "profiles/sq_counters.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES ...)"}
 
 
 def kernel_variant(flat):
@@ -275,7 +277,7 @@ def main():
         }
         if flat is not None:
             out["roofline"]["flat_scan"] = flat
-        valu = valu_from_profile(args.workload, float(np.mean(kernel_ms)))
+        valu = valu_from_profile(args.workload, seg / args.steps)
         if valu is not None and valu["spp_per_launch"] == sps:
             out["roofline"]["valu"] = valu
         if world == 1 and not args.no_cpu_baseline:
