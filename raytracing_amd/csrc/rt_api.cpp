@@ -277,17 +277,17 @@ int rt_render(rt_ctx *ctx, const rt_params *p) {
     // one launch per sample_chunk samples: the per-sample colours of a launch are staged
     // in d_samples before they are added to the sums in sample order
     rt_params part = *p;
-    // development aid: RT_HIP_UNIT_ROWS=8|4|2|1 fixes the rows of a tile per work unit
+    // development aid: RT_HIP_UNIT_PX=2|4|8|16|32|64 fixes the pixels of a tile per work unit
     // (default: by launch size, see rtk_launch_render)
-    const char *ur = std::getenv("RT_HIP_UNIT_ROWS");
-    const int rows = ur ? std::atoi(ur) : 0;
-    const int unit_rows_log2 = rows == 8 ? 3 : rows == 4 ? 2 : rows == 2 ? 1 : rows == 1 ? 0 : -1;
+    const char *up = std::getenv("RT_HIP_UNIT_PX");
+    int unit_px_log2 = -1;
+    for (int k = 1; up && k <= 6; ++k) if (std::atoi(up) == (1 << k)) unit_px_log2 = k;
     for (uint32_t done = 0; done < p->sample_count; done += c->sample_chunk) {
         part.sample_begin = p->sample_begin + done;
         part.sample_count = std::min(c->sample_chunk, p->sample_count - done);
         fr.queue = c->d_queue + (c->launches & 1u);
         fr.queue_next = c->d_queue + ((c->launches + 1u) & 1u);
-        HIP_TRY(c, rtk_launch_render(c->dsc, c->cam, part, fr, n_bands, c->n_cus, unit_rows_log2, c->stream));
+        HIP_TRY(c, rtk_launch_render(c->dsc, c->cam, part, fr, n_bands, c->n_cus, unit_px_log2, c->stream));
         c->launches += 1u;     // only a launch that ran has zeroed the other counter
     }
     return RT_OK;

@@ -88,7 +88,7 @@ struct DevFrame {
 };
 
 hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_params &p,
-                             const DevFrame &fr, uint32_t n_bands, uint32_t n_cus, int unit_rows_log2,
+                             const DevFrame &fr, uint32_t n_bands, uint32_t n_cus, int unit_px_log2,
                              hipStream_t stream);
 hipError_t rtk_launch_pack_bands(const float4 *accum, uint32_t *out, uint32_t W, uint32_t H,
                                  uint32_t band_begin, uint32_t band_stride, uint32_t n_bands,

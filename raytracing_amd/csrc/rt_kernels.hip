@@ -26,6 +26,9 @@
 
 #include "rt_device.h"
 
+#ifndef RTK_SUM_BATCH
+#define RTK_SUM_BATCH 16u    // staged colours fetched at a time when a unit is added up
+#endif
 #ifndef RTK_TREE_WAVES
 #define RTK_TREE_WAVES 8
 #endif
@@ -850,7 +853,7 @@ template <int MODES>
 // waves per SIMD without spills (one 12-wave workgroup per CU) -2 %, two waves -24 %, 4-wave
 // workgroups with a 16 KB tree copy -5 %, 96 VGPRs for five waves per SIMD -40 %.
 __global__ __launch_bounds__(waves_of(MODES) * 64, RTK_OCC)
-void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_t n_bands, uint32_t unit_rows_log2) {
+void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_t n_bands, uint32_t unit_px_log2) {
     __shared__ Lds<MODES> lds;
     const SceneView sc = view_of(dsc, fr.segments);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -871,8 +874,9 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
 
     // units of this launch: tile by tile along the band, the row groups of a tile one after the other
     const uint32_t tiles_x = (W + TILE - 1u) / TILE;
-    const uint32_t unit_rows = 1u << unit_rows_log2, unit_px_log2 = 3u + unit_rows_log2;
-    const uint32_t sub_log2 = 3u - unit_rows_log2;               // units per tile, log2
+    const uint32_t unit_px = 1u << unit_px_log2;                  // 2 .. 64 pixels: part of a tile row, or whole rows
+    const uint32_t unit_cols = unit_px < 8u ? unit_px : 8u, unit_rows = unit_px < 8u ? 1u : unit_px >> 3;
+    const uint32_t sub_log2 = 6u - unit_px_log2;                  // units per tile, log2
     const uint32_t n_units = (tiles_x * n_bands) << sub_log2;
 
     // Per-lane state that lives across the scan is kept small (registers are what limits the
@@ -897,7 +901,7 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
         const uint32_t slot = it >> ITEM_BITS, q = it & ((1u << ITEM_BITS) - 1u);
         const uint32_t xy = ring.xy[slot];
         Where w;
-        w.i = (xy & 0xffffu) + (q & 7u);
+        w.i = (xy & 0xffffu) + (q & (unit_cols - 1u));
         w.j = (xy >> 16) + ((q >> 3) & (unit_rows - 1u));
         w.s = p.sample_begin + (q >> unit_px_log2);
         return w;
@@ -926,7 +930,7 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
         const uint32_t xy = ring.xy[slot];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const uint32_t pi = (xy & 0xffffu) + (lane & 7u), pj = (xy >> 16) + (lane >> 3);
-        if ((lane >> 3) < unit_rows && pi < W && pj < H) {
+        if ((lane & 7u) < unit_cols && (lane >> 3) < unit_rows && pi < W && pj < H) {
             const size_t pix_out = (size_t)(H - 1u - pj) * W + pi;   // src/raytracer.rs:265
             float4 acc = fr.accum[pix_out];
             V3 px = mk(acc.x, acc.y, acc.z);
@@ -934,13 +938,13 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
             const uint32_t n_add = p.max_bounces > 0 ? p.sample_count : 0u;
             const float4 *src = fr.samples + pix_out;
             uint32_t k = 0;
-            // eight loads on the way at a time; the additions keep their order (src/raytracer.rs:262)
-            for (; k + 8u <= n_add; k += 8u) {
-                float4 c[8];
+            // RTK_SUM_BATCH loads on the way at a time; the additions keep their order (src/raytracer.rs:262)
+            for (; k + RTK_SUM_BATCH <= n_add; k += RTK_SUM_BATCH) {
+                float4 c[RTK_SUM_BATCH];
 #pragma unroll
-                for (uint32_t m = 0; m < 8u; ++m) c[m] = src[(size_t)(k + m) * n_px];
+                for (uint32_t m = 0; m < RTK_SUM_BATCH; ++m) c[m] = src[(size_t)(k + m) * n_px];
 #pragma unroll
-                for (uint32_t m = 0; m < 8u; ++m) px = px + mk(c[m].x, c[m].y, c[m].z);
+                for (uint32_t m = 0; m < RTK_SUM_BATCH; ++m) px = px + mk(c[m].x, c[m].y, c[m].z);
             }
             for (; k < n_add; ++k) {
                 const float4 c = src[(size_t)k * n_px];
@@ -967,8 +971,9 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
                 const uint32_t t = u >> sub_log2, sub = u & ((1u << sub_log2) - 1u);
                 const uint32_t by = t / tiles_x, tx = t - by * tiles_x;
                 const uint32_t band = p.band_begin + by * p.band_stride;
-                const uint32_t x0 = tx * TILE, y0 = band * TILE + sub * unit_rows;
-                const uint32_t vw = W - x0 < (uint32_t)TILE ? W - x0 : (uint32_t)TILE;
+                const uint32_t first = sub << unit_px_log2;                 // the unit's first pixel of the tile, row-major
+                const uint32_t x0 = tx * TILE + (first & 7u), y0 = band * TILE + (first >> 3);
+                const uint32_t vw = x0 >= W ? 0u : (W - x0 < unit_cols ? W - x0 : unit_cols);
                 const uint32_t vh = y0 >= H ? 0u : (H - y0 < unit_rows ? H - y0 : unit_rows);
                 const uint32_t left = p.max_bounces > 0u ? vw * vh * p.sample_count : 0u;
                 if (lane == 0u) { ring.xy[slot] = x0 | (y0 << 16); ring.left[slot] = left; }
@@ -987,7 +992,7 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
         }
     };
 #ifdef RTK_TIMES
-    unsigned long long tm_scan = 0, tm_rest = 0, tm_done = 0, tm_fetch = 0;
+    unsigned long long tm_scan = 0, tm_rest = 0, tm_done = 0, tm_fetch = 0, tm_fin = 0;
 #endif
     fetch(true);
 
@@ -1015,9 +1020,6 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
             const V3 ud = unit(ray.d);
             V3 c;
             uint32_t n_hits = n_stack;
-#ifdef RTK_TIMES
-            const unsigned long long tm2 = __builtin_readcyclecounter();
-#endif
             if (h.kind >= 0) {
                 uint32_t mat = shade_hit(sc, lds.sphere, ray, ud, h, sp_bn, path_counter, path_key_at(at), n_stack);
                 lds.mat_stack[wave][n_stack][lane] = mat;
@@ -1029,6 +1031,9 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
                 c = sky(ud, gamma);
                 done = true;
             }
+#ifdef RTK_TIMES
+            const unsigned long long tm2 = __builtin_readcyclecounter();
+#endif
             if (done) {
                 // attenuation * ray_colour(...), innermost product first (src/raytracer.rs:79)
                 // (four entries per round: their fetches overlap, the products keep their order)
@@ -1066,9 +1071,13 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (left == 0u) finish_unit(slot);
         }
+#ifdef RTK_TIMES
+        const unsigned long long tm4 = __builtin_readcyclecounter();
+        tm_fin += tm4 - tm3;
+#endif
         if (__builtin_amdgcn_ballot_w64(!alive) != 0ull) fetch(!alive);
 #ifdef RTK_TIMES
-        tm_fetch += __builtin_readcyclecounter() - tm3;
+        tm_fetch += __builtin_readcyclecounter() - tm4;
         tm_rest += __builtin_readcyclecounter() - tm1;
 #endif
     }
@@ -1077,6 +1086,7 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
     if (lane == 0) {
         atomicAdd(fr.segments + 4, tm_scan); atomicAdd(fr.segments + 7, tm_rest);
         atomicAdd(fr.segments + 5, tm_done); atomicAdd(fr.segments + 6, tm_fetch);
+        atomicAdd(fr.segments + 3, tm_fin);
     }
 #endif
     if (lane == 0 && n_seg != 0) atomicAdd(fr.segments, (unsigned long long)n_seg);
@@ -1132,27 +1142,32 @@ hipError_t rtk_launch_pack_bands(const float4 *accum, uint32_t *out, uint32_t W,
     return hipGetLastError();
 }
 hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_params &p,
-                             const DevFrame &fr, uint32_t n_bands, uint32_t n_cus, int unit_rows_log2,
+                             const DevFrame &fr, uint32_t n_bands, uint32_t n_cus, int unit_px_log2,
                              hipStream_t stream) {
     const uint32_t waves = (uint32_t)rtk::waves_of((int)(sc.modes & 3u));
     const uint32_t tiles_x = (p.width + rtk::TILE - 1u) / rtk::TILE;
     const uint64_t n_tiles = (uint64_t)tiles_x * n_bands;
     const uint64_t resident = (uint64_t)n_cus * (4u * RTK_OCC / waves);   // workgroups the chip holds at once
     if (p.sample_count > 64u || p.width > 65536u || p.height > 65536u) return hipErrorInvalidValue;
-    // Rows of a tile per work unit: the fewest that still give a unit 512 work items (eight per
-    // lane).  Measured on 4K frames at 64 samples per launch, whole frame / one eighth of the
-    // bands: 1 row 133.0 / 17.8 ms, 2 rows 132.8 / 19.1, 4 rows 135.3 / 21.9, 8 rows 139.1 / 26.5
-    // (10,000 spheres); the million-triangle scene 66.7 / 9.6 ms with 1 row, 75.9 / 22.1 with 8.
-    if (unit_rows_log2 < 0 || unit_rows_log2 > 3) {
-        unit_rows_log2 = 0;
-        while (unit_rows_log2 < 3 && ((uint64_t)p.sample_count << (3 + unit_rows_log2)) < 512u) ++unit_rows_log2;
+    // Pixels of a tile per work unit (part of a row, or whole rows): the fewest that still give a
+    // unit 512 work items (eight per lane).  Measured on 4K frames at 64 samples per launch, whole
+    // frame / one eighth of the bands, 10,000 spheres: 4 pixels 135.2 / 17.4 ms, 8 pixels 132.2 /
+    // 17.8, 16 pixels 132.1 / 19.1, 32 pixels 135.3 / 21.9, 64 pixels 139.1 / 26.5; the
+    // million-triangle scene 69.8 / 9.2 ms with 4, 64.9 / 9.4 with 8, 75.9 / 22.1 with 64.
+    if (unit_px_log2 < 1 || unit_px_log2 > 6) {
+        unit_px_log2 = 3;
+        while (unit_px_log2 < 6 && ((uint64_t)p.sample_count << unit_px_log2) < 512u) ++unit_px_log2;
+        // a small launch (one GPU's share of a frame): half as long units, so that a wave still
+        // gets a few dozen of them
+        if ((n_tiles << (6 - unit_px_log2)) < 48u * resident * waves && ((uint64_t)p.sample_count << unit_px_log2) >= 512u)
+            --unit_px_log2;
     }
-    const uint64_t n_units = n_tiles << (3 - unit_rows_log2);
+    const uint64_t n_units = n_tiles << (6 - unit_px_log2);
     if (n_units >= 0xffffffffull - resident * waves) return hipErrorInvalidValue;
     // as many workgroups as the chip holds, fewer when there are not that many work units
     const uint64_t groups = std::max<uint64_t>(1u, std::min<uint64_t>(resident, (n_units + waves - 1u) / waves));
     dim3 grid((uint32_t)groups, 1, 1), block(waves * 64, 1, 1);
-    const uint32_t r = (uint32_t)unit_rows_log2;
+    const uint32_t r = (uint32_t)unit_px_log2;
     switch (sc.modes & 3u) {
     case 0: hipLaunchKernelGGL(rtk::render_tiles<0>, grid, block, 0, stream, sc, cam, p, fr, n_bands, r); break;
     case 1: hipLaunchKernelGGL(rtk::render_tiles<1>, grid, block, 0, stream, sc, cam, p, fr, n_bands, r); break;
