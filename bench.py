@@ -15,6 +15,11 @@ is exactly two such frames.  The frame is split over the N ranks by interleaved 
 
 Rank 0 prints ONE JSON line.  `value` is Mrays/s over all ranks, a ray being one
 path segment (one closest-hit query over the list), counted on the device.
+
+Rehearsal of the multi-rank path on a box with one GPU (not a measurement):
+RT_BENCH_REHEARSAL=1 puts every rank on device 0, gathers through gloo and host
+memory instead of RCCL, and has rank 0 render the same samples alone and compare
+the gathered frame with its own, pixel for pixel.
 """
 import argparse
 import json
@@ -160,8 +165,13 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: librt_hip.so has no CPU path")
+    rehearsal = os.environ.get("RT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 and rehearsal:
+        dist.init_process_group("gloo")
+    elif world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -196,8 +206,13 @@ def main():
         torch.cuda.current_stream().synchronize()   # the previous step's gather has read `block`
         r.export_packed_bands(block.data_ptr(), block.numel(), rank, world)
         r.sync()
-        if world > 1:
+        if world > 1 and rehearsal:
+            parts = [torch.empty(block.shape, dtype=block.dtype) for _ in range(world)]
+            dist.all_gather(parts, block.cpu())
+            gathered.copy_(torch.cat(parts))
+        elif world > 1:
             dist.all_gather_into_tensor(gathered, block)
+        if world > 1:
             frame[0] = multi_gpu.compose(gathered.view(world, max_bands * 8, w), h)   # display order, every rank
         return ms
 
@@ -221,12 +236,30 @@ def main():
     seg = r.ray_count() - seg0
 
     if world > 1:
-        t = torch.tensor([dt, float(seg), float(np.mean(kernel_ms))], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, float(seg), float(np.mean(kernel_ms))], dtype=torch.float64,
+                         device="cpu" if rehearsal else "cuda")
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt = float(tmax[0]); seg_total = int(tsum[1]); kern_ms_max = float(tmax[2])
     else:
         seg_total = seg; kern_ms_max = float(np.mean(kernel_ms))
+
+    if rehearsal and world > 1 and rank == 0:
+        # the same samples on one renderer, all bands: the gathered frame must be identical
+        alone = Renderer(0, tables)
+        alone.set_scene(wl["flat"]); alone.set_camera(wl["camera"]); alone.begin_frame(w, h)
+        for k in range(args.steps):
+            begin = (k % max(1, spp // sps)) * sps
+            alone.render(make_params(w, h, spp=spp, sample_begin=begin, sample_count=sps))
+        want = alone.read_packed()
+        got = frame[0].cpu().numpy().view(np.uint32)
+        same = bool(np.array_equal(got.reshape(want.shape), want))
+        alone_segments = alone.ray_count()
+        alone.close()
+        print("rehearsal: gathered frame of %d ranks %s the single-renderer frame; segments %d vs %d"
+              % (world, "equals" if same else "DIFFERS FROM", seg_total, alone_segments), file=sys.stderr, flush=True)
+        if not same or seg_total != alone_segments:
+            sys.exit(1)
 
     flat = None
     if rank == 0 and world == 1 and not args.no_flat_probe and (wl["flat"].counts["n_spheres"] >= 64):
