@@ -118,6 +118,30 @@ def test_sample_ranges_longer_than_one_launch(renderer, oracle, tables):
     assert_same(one, render_oracle(oracle, tables, flat, cam, [make_params(40, 24, spp=150)]), oracle)
 
 
+@pytest.mark.parametrize("unit_px", [2, 4, 8, 16, 32, 64])
+def test_every_work_unit_size_gives_the_same_picture(renderer, oracle, tables, unit_px):
+    """the launch hands out parts of 8x8 tiles (2 to 64 pixels x the samples of the launch) to
+    the waves; whatever the size, and with a frame whose right and top tiles are partial
+    (61 x 43), the sums are those of the oracle: 3 samples (units of a few items, several in
+    flight per wave), 64 and 70 samples (a second launch of 6), two bands out of three, and a
+    depth budget of 0 (units with nothing to trace)"""
+    import os
+    flat = Scene.get_scene().flatten()
+    cam = Scene.get_camera(aperture=0.1)
+    w, h = 61, 43
+    cases = [[make_params(w, h, spp=3)], [make_params(w, h, spp=64)], [make_params(w, h, spp=70)],
+             [make_params(w, h, spp=4, band_begin=g, band_stride=3) for g in (0, 2)],
+             [make_params(w, h, spp=2, max_bounces=0)]]
+    want = [render_oracle(oracle, tables, flat, cam, c) for c in cases]
+    os.environ["RT_HIP_UNIT_PX"] = str(unit_px)
+    try:
+        got = [render_gpu(renderer, flat, cam, c) for c in cases]
+    finally:
+        del os.environ["RT_HIP_UNIT_PX"]
+    for g, o in zip(got, want):
+        assert_same(g, o, oracle)
+
+
 def test_band_partition(renderer, oracle, tables):
     """the multi-GPU split: bands b % 3 == g rendered separately add up to the frame, and
     rt_export_packed_bands lays each share out as the gather expects"""
