@@ -507,6 +507,7 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
     const float khx = -((ray.o.x - pad) * ix), khy = -((ray.o.y - pad) * iy), khz = -((ray.o.z - pad) * iz);
     const uint32_t top = run.n_levels - 1u;
     const RT_CONST_AS f4 *nodes = sc.tree_rec;
+    const float t_low = __builtin_fminf(t_min, 0.0f);   // no hit is accepted in front of t_min
 
     for (uint32_t ts = 0; ts < run.top_steps; ++ts) {
         uint32_t L = top, st = ts;
@@ -527,8 +528,8 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
 #pragma unroll
                     for (int q = 0; q < 12; ++q) nd[q] = src[q];
                 }
-                uint32_t sign_bits = 0u;
-                uint32_t nearest = 0xffffffffu;   // min over surviving children of (entry distance | index)
+                uint32_t live = 0u;               // children the ray may hit
+                uint32_t nearest = 0xffffffffu;   // min over them of (entry distance | index)
 #pragma unroll
                 for (int pr = 0; pr < 4; ++pr) {
                     const f4 X = nd[3 * pr], Y = nd[3 * pr + 1], Z = nd[3 * pr + 2];   // lo0, lo1, hi0, hi1
@@ -536,32 +537,35 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
                     const f2 tlx = __builtin_elementwise_fma(X.xy, ix2, (f2){klx, klx}), thx = __builtin_elementwise_fma(X.zw, ix2, (f2){khx, khx});
                     const f2 tly = __builtin_elementwise_fma(Y.xy, iy2, (f2){kly, kly}), thy = __builtin_elementwise_fma(Y.zw, iy2, (f2){khy, khy});
                     const f2 tlz = __builtin_elementwise_fma(Z.xy, iz2, (f2){klz, klz}), thz = __builtin_elementwise_fma(Z.zw, iz2, (f2){khz, khz});
-                    float tn[2], nn[2];
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
                         const float ax_ = c ? tlx.y : tlx.x, bx_ = c ? thx.y : thx.x;
                         const float ay_ = c ? tly.y : tly.x, by_ = c ? thy.y : thy.x;
                         const float az_ = c ? tlz.y : tlz.x, bz_ = c ? thz.y : thz.x;
-                        const float enter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax_, bx_), __builtin_fminf(ay_, by_)),
-                                                            __builtin_fmaxf(__builtin_fminf(az_, bz_), 0.0f));
-                        const float leave = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax_, bx_), __builtin_fmaxf(ay_, by_)),
-                                                            __builtin_fminf(__builtin_fmaxf(az_, bz_), h.t));
-                        tn[c] = enter;
-                        nn[c] = leave - enter;   // >= 0: some point of the ray in front of the best hit is inside
+                        // [enter, leave] = [t_low, closest_so_far] cut down by the three slabs.  The
+                        // median of a slab's two plane distances and a bound is that bound clamped
+                        // into the slab: where the slab overlaps [enter, leave] both come out as
+                        // max(enter, near) and min(leave, far); where it does not they meet in one
+                        // point and stay together through the other slabs.  A box is kept only if
+                        // enter < leave; an interval of length zero is at most a touch of the widened
+                        // box, which no primitive inside reaches.
+                        float enter = t_low, leave = h.t;
+                        enter = __builtin_amdgcn_fmed3f(ax_, bx_, enter); leave = __builtin_amdgcn_fmed3f(ax_, bx_, leave);
+                        enter = __builtin_amdgcn_fmed3f(ay_, by_, enter); leave = __builtin_amdgcn_fmed3f(ay_, by_, leave);
+                        enter = __builtin_amdgcn_fmed3f(az_, bz_, enter); leave = __builtin_amdgcn_fmed3f(az_, bz_, leave);
+                        // all ones where enter < leave
+                        const uint32_t m = (uint32_t)((int32_t)__float_as_uint(enter - leave) >> 31);
+                        const uint32_t child = (uint32_t)(2 * pr + c);
+                        live |= m & (1u << child);
+                        // enter >= 0 orders like its bit pattern; the low three bits carry the child
+                        // index, a rejected child becomes all ones
+                        const uint32_t key = (__float_as_uint(enter) & ~7u) | child;
+                        nearest = min(nearest, (key & m) | ~m);
                     }
-                    // enter >= 0 orders like its bit pattern; the low three bits carry the child
-                    // index, a rejected child (negative nn) becomes all ones
-                    const uint32_t s0 = (uint32_t)((int32_t)__float_as_uint(nn[0]) >> 31);
-                    const uint32_t s1 = (uint32_t)((int32_t)__float_as_uint(nn[1]) >> 31);
-                    sign_bits |= s0 & (1u << (2 * pr));
-                    sign_bits |= s1 & (1u << (2 * pr + 1));
-                    const uint32_t kx = ((__float_as_uint(tn[0]) & ~7u) | (uint32_t)(2 * pr)) | s0;
-                    const uint32_t ky = ((__float_as_uint(tn[1]) & ~7u) | (uint32_t)(2 * pr + 1)) | s1;
-                    nearest = min(nearest, min(kx, ky));
                 }
                 // children past the end of the level below do not exist
                 const uint32_t have = min(8u, tbl.count[L] - 8u * st);
-                uint32_t bits = ~sign_bits & ((1u << have) - 1u);
+                uint32_t bits = live & ((1u << have) - 1u);
                 if (L != 0u && bits != 0u) {
                     // descend into the surviving child the ray enters first (so that a near
                     // hit bounds the rest of the walk early), remember the others

@@ -146,6 +146,31 @@ def test_camera_inside_a_dense_cluster(renderer, oracle, tables):
           [make_params(96, 64, spp=3)])
 
 
+@pytest.mark.parametrize("t_min", [-4.0, -0.5, 0.0, 0.5, 3.0])
+def test_t_min_other_than_the_reference_value(renderer, oracle, tables, t_min):
+    """Hittable::hit takes t_min from its caller (0.001 in ray_colour, src/raytracer.rs:75); with a
+    negative one, hits behind the ray origin count (src/geometry/mod.rs:74-79), so the boxes behind
+    the origin must not be skipped; with a large one, near hits are passed over for their second
+    root or for farther primitives"""
+    rng = np.random.default_rng(15)
+    s = HittableList()
+    for _ in range(300):
+        s.add(Sphere(tuple(rng.uniform(-4, 4, 3)), float(rng.uniform(0.2, 0.7)), _mat(rng)))
+    for _ in range(150):
+        a = rng.uniform(-4, 4, 3)
+        s.add(Triangle(tuple(a), tuple(a + rng.uniform(-1, 1, 3)), tuple(a + rng.uniform(-1, 1, 3)), _mat(rng)))
+    flat = s.flatten()
+    cam = _cam((0.3, 0.2, 0.5), look_at=(1.0, 0.4, -2.0), fov=70.0)      # inside the cluster
+    p = [make_params(72, 48, spp=3, t_min=t_min)]
+    orc = render_oracle(oracle, tables, flat, cam, p)
+    assert_same(render_gpu(renderer, flat, cam, p), orc, oracle)
+    os.environ["RT_HIP_FLAT_SCAN"] = "1"
+    try:
+        assert_same(render_gpu(renderer, flat, cam, p), orc, oracle)
+    finally:
+        del os.environ["RT_HIP_FLAT_SCAN"]
+
+
 def _null_camera(direction=(0.0, 0.0, 0.0)):
     """every pixel gets the same ray origin (0,0,5) and `direction`"""
     cam = _lib.rt_camera()
