@@ -854,8 +854,9 @@ template <int MODES>
 #endif
 // Two 8-wave workgroups per CU: four waves per SIMD, at most 128 VGPRs each (some per-item
 // state is spilled around the walk).  Measured alternatives on the 10,000-sphere frame: three
-// waves per SIMD without spills (one 12-wave workgroup per CU) -2 %, two waves -24 %, 4-wave
-// workgroups with a 16 KB tree copy -5 %, 96 VGPRs for five waves per SIMD -40 %.
+// waves per SIMD without spills (one 12-wave workgroup per CU) -14 %, 4-wave workgroups with
+// a 16 KB tree copy -5 %, 16-wave workgroups the same, 96 VGPRs for five waves per SIMD -40 %;
+// 6- or 10-wave workgroups fit only once per CU.
 __global__ __launch_bounds__(waves_of(MODES) * 64, RTK_OCC)
 void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_t n_bands, uint32_t unit_px_log2) {
     __shared__ Lds<MODES> lds;
