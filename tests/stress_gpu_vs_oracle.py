@@ -1,0 +1,57 @@
+"""Fuzz: the GPU library against the CPU oracle on the random scenes of
+tools/stress_tree_vs_list.py (spheres, triangles, cubes and planes in mixed list order,
+slivers, lattices of touching spheres, coplanar sheets, extents from 0.1 to 1000, cameras
+inside and far outside), at a frame size the oracle traces in a fraction of a second
+(96 x 54, 2 samples), with a random t_min now and then.  Sums, primary ids, packed pixels
+and segment counts must be identical.  Not collected by pytest; run by
+tests/test_gpu_tree.py for a few seconds and by hand for longer:
+    python tests/stress_gpu_vs_oracle.py [seconds] [seed0]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from raytracing_amd import Renderer, load_tables, make_params  # noqa: E402
+from tests import oracle_lib  # noqa: E402
+from tools.stress_tree_vs_list import scene  # noqa: E402
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    tables = load_tables()
+    r = Renderer(0, tables)
+    orc = oracle_lib.load()
+    threads = min(16, os.cpu_count() or 1)
+    t0 = time.time()
+    k = bad = 0
+    rays = 0
+    while time.time() - t0 < budget:
+        rng = np.random.default_rng(seed0 + k)
+        flat, cam = scene(rng)
+        t_min = 0.001 if rng.random() < 0.8 else float(rng.choice([-1.0, 0.0, 0.05, 2.0]))
+        p = make_params(96, 54, spp=2, seed=k, t_min=t_min)
+        o_acc, o_ids, o_seg = orc.render(flat, cam, tables, p, threads=threads)
+        r.set_scene(flat); r.set_camera(cam); r.begin_frame(p.width, p.height); r.render(p)
+        acc, ids, seg, packed = r.read_accum(), r.read_primary_ids(), r.ray_count(), r.read_packed()
+        a, b = acc.view(np.uint32), np.ascontiguousarray(o_acc[..., :3]).view(np.uint32)
+        nan = np.isnan(acc) & np.isnan(o_acc[..., :3])          # NaN payloads may differ
+        same = (np.array_equal(a[~nan], b[~nan]) and np.array_equal(ids, o_ids) and seg == o_seg
+                and np.array_equal(packed, orc.pack(o_acc)))
+        rays += seg
+        if not same:
+            bad += 1
+            print("MISMATCH seed", seed0 + k, "t_min", t_min, "sums", int((a != b)[~nan].sum()),
+                  "ids", int((ids != o_ids).sum()), "segments", seg, o_seg, flush=True)
+        k += 1
+        if k % 20 == 0:
+            print("scenes", k, "segments %.3g" % rays, "mismatches", bad, "t %.0f s" % (time.time() - t0), flush=True)
+    print("DONE scenes", k, "segments %.4g" % rays, "mismatches", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -348,3 +348,14 @@ def test_fuzz_tree_against_list_order_scan():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_tree_vs_list.py"), "20", "100000"],
                          capture_output=True, text=True, timeout=200)
     assert out.returncode == 0 and "mismatches 0" in out.stdout.splitlines()[-1], out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_fuzz_gpu_against_oracle():
+    """the same random scenes at 96x54 against the CPU oracle (tests/stress_gpu_vs_oracle.py), with a
+    random t_min now and then: sums, ids, packed pixels and segment counts identical"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "stress_gpu_vs_oracle.py"), "10", "700000"],
+                         capture_output=True, text=True, timeout=200)
+    assert out.returncode == 0 and "mismatches 0" in out.stdout.splitlines()[-1], out.stdout[-2000:] + out.stderr[-2000:]
