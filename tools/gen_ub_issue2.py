@@ -7,6 +7,34 @@ V = {
  "add vgpr": ["v_add_f32_e32 {d}, {a}, {b}"] * 8,
  "sub vgpr": ["v_sub_f32_e32 {d}, {a}, {b}"] * 8,
  "max vgpr": ["v_max_f32_e32 {d}, {a}, {b}"] * 8,
+ "min vgpr": ["v_min_f32_e32 {d}, {a}, {b}"] * 8,
+ "max3 vgpr": ["v_max3_f32 {d}, {a}, {b}, {b}"] * 8,
+ "med3 vgpr": ["v_med3_f32 {d}, {a}, {b}, {b}"] * 8,
+ "med3 vgpr, own dest as src2": ["v_med3_f32 {d}, {a}, {b}, {d}"] * 8,
+ "alt med3/pk_fma/med3/med3": ["v_med3_f32 {d}, {a}, {b}, {b}", "v_pk_fma_f32 {dp}, {ap}, {bp}, {bp}", "v_med3_f32 {d}, {a}, {b}, {b}", "v_med3_f32 {d}, {a}, {b}, {b}"] * 2,
+ "alt max/min": ["v_max_f32_e32 {d}, {a}, {b}", "v_min_f32_e32 {d}, {a}, {b}"] * 4,
+ "ashr vgpr": ["v_ashrrev_i32_e32 {d}, 31, {a}"] * 8,
+ "bitop3 vgpr": ["v_bitop3_b32 {d}, {a}, {b}, {b} bitop3:0xfd"] * 8,
+ "alt med3/sub": ["v_med3_f32 {d}, {a}, {b}, {b}", "v_sub_f32_e32 {d}, {a}, {b}"] * 4,
+ "alt med3/ashr": ["v_med3_f32 {d}, {a}, {b}, {b}", "v_ashrrev_i32_e32 {d}, 31, {a}"] * 4,
+ "alt med3(3 distinct)/sub": ["v_med3_f32 {d}, {a}, {b}, {d}", "v_sub_f32_e32 {d}, {a}, {b}"] * 4,
+ "alt max/mul": ["v_max_f32_e32 {d}, {a}, {b}", "v_mul_f32_e32 {d}, {a}, {b}"] * 4,
+ "alt pk_fma/ashr": ["v_pk_fma_f32 {dp}, {ap}, {bp}, {bp}", "v_ashrrev_i32_e32 {d}, 31, {a}"] * 4,
+ "alt med3/med3/sub/and": ["v_med3_f32 {d}, {a}, {b}, {b}", "v_med3_f32 {d}, {a}, {b}, {b}", "v_sub_f32_e32 {d}, {a}, {b}", "v_and_b32_e32 {d}, {a}, {b}"] * 2,
+ "cndmask vcc": ["v_cndmask_b32_e32 {d}, {a}, {b}, vcc"] * 8,
+ "cndmask sgpr pair": ["v_cndmask_b32_e64 {d}, {a}, {b}, s[20:21]"] * 8,
+ "cmp then cndmask vcc": ["v_cmp_gt_f32_e32 vcc, {a}, {b}", "v_cndmask_b32_e32 {d}, {a}, {b}, vcc"] * 4,
+ "cmp e64 then cndmask sgpr": ["v_cmp_gt_f32_e64 s[22:23], {a}, {b}", "v_cndmask_b32_e64 {d}, {a}, {b}, s[22:23]"] * 4,
+ "cmp, 3 mul, cndmask": ["v_cmp_gt_f32_e32 vcc, {a}, {b}", "v_mul_f32_e32 {d}, {a}, {b}", "v_mul_f32_e32 {d}, {a}, {b}", "v_cndmask_b32_e32 {d}, {a}, {b}, vcc"] * 2,
+ "bfi": ["v_bfi_b32 {d}, {a}, {b}, {b}"] * 8,
+ "sqrt": ["v_sqrt_f32_e32 {d}, {a}"] * 8,
+ "rcp": ["v_rcp_f32_e32 {d}, {a}"] * 8,
+ "div_scale": ["v_div_scale_f32 {d}, vcc, {a}, {b}, {a}"] * 8,
+ "div_fmas": ["v_div_fmas_f32 {d}, {a}, {b}, {b}"] * 8,
+ "div_fixup": ["v_div_fixup_f32 {d}, {a}, {b}, {b}"] * 8,
+ "min_u32": ["v_min_u32_e32 {d}, {a}, {b}"] * 8,
+ "and_or": ["v_and_or_b32 {d}, {a}, {b}, {b}"] * 8,
+ "lshl_add": ["v_lshl_add_u32 {d}, {a}, 3, {b}"] * 8,
  "mov vgpr": ["v_mov_b32_e32 {d}, {a}"] * 8,
  "and vgpr": ["v_and_b32_e32 {d}, {a}, {b}"] * 8,
  "mul sgpr src0": ["v_mul_f32_e32 {d}, {s}, {b}"] * 8,
@@ -47,7 +75,7 @@ for vi, name in enumerate(names):
                                   s="s20", sp="s[20:21]"))
     body = "\\n ".join(lines)
     # destinations are 64-bit pairs; plain f32 ops write the low half
-    out.append('    if (V == %d) asm volatile("%s" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "v"(ap), "v"(bp) : "vcc");' % (vi, body))
+    out.append('    if (V == %d) asm volatile("%s" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "v"(ap), "v"(bp) : "vcc", "s20", "s21", "s22", "s23");' % (vi, body))
 out += ['  }', '  out[blockIdx.x * 256 + threadIdx.x] = r0.x + r1.x + r2.x + r3.x + r4.y + r5.x + r6.x + r7.x + q0 + q1 + q2 + q3 + q4 + q5 + q6 + q7;', '}',
         'template <int V> void run(const char *name, float *out) {',
         '  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); const int iters = 10000;',
