@@ -833,8 +833,9 @@ __device__ __forceinline__ V3 sky(V3 ud, bool gamma) {
 // calculate_some_pxls + ray_colour, src/raytracer.rs:232-271 and :68-92.
 //
 // The launch is a fixed number of resident workgroups; every wavefront on its own takes work
-// units from one global queue until the queue is empty.  A unit is 8, 4, 2 or 1 rows of an 8x8
-// tile (chosen per launch, see rtk_launch_render) x all samples of the launch; its work items
+// units from one global queue until the queue is empty.  A unit is 2 to 64 pixels of an 8x8 tile
+// (part of a row, or whole rows; chosen per launch, see rtk_launch_render) x all samples of the
+// launch; its work items
 // (pixel, sample), sample-major, are handed to the wave's lanes one at a time: a lane whose
 // path ends takes the next item, whatever pixel it belongs to, and when a unit runs out of
 // items the wave starts the next unit at once while its longer paths are still on the way (up
@@ -877,7 +878,7 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
     const size_t n_px = (size_t)W * H;
     UnitRing &ring = lds.ring[wave];
 
-    // units of this launch: tile by tile along the band, the row groups of a tile one after the other
+    // units of this launch: tile by tile along the band, the parts of a tile one after the other
     const uint32_t tiles_x = (W + TILE - 1u) / TILE;
     const uint32_t unit_px = 1u << unit_px_log2;                  // 2 .. 64 pixels: part of a tile row, or whole rows
     const uint32_t unit_cols = unit_px < 8u ? unit_px : 8u, unit_rows = unit_px < 8u ? 1u : unit_px >> 3;
