@@ -507,7 +507,11 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
     const float khx = -((ray.o.x - pad) * ix), khy = -((ray.o.y - pad) * iy), khz = -((ray.o.z - pad) * iz);
     const uint32_t top = run.n_levels - 1u;
     const RT_CONST_AS f4 *nodes = sc.tree_rec;
-    const float t_low = __builtin_fminf(t_min, 0.0f);   // no hit is accepted in front of t_min
+    // no hit is accepted in front of t_min; the bound lies a little below it, so that a box
+    // holding a hit at exactly t_min (and at closest_so_far, a tie) keeps an interval of its own
+    // (0 for the usual positive t_min: entry distances that are not negative order like their
+    // bit patterns, which the choice of the nearest child relies on)
+    const float t_low = t_min > 0.0f ? 0.0f : t_min - __builtin_fmaxf(__builtin_fabsf(t_min) * 9.5367431640625e-07f, 1e-30f);
 
     for (uint32_t ts = 0; ts < run.top_steps; ++ts) {
         uint32_t L = top, st = ts;

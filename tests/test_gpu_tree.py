@@ -171,6 +171,29 @@ def test_t_min_other_than_the_reference_value(renderer, oracle, tables, t_min):
         del os.environ["RT_HIP_FLAT_SCAN"]
 
 
+def test_ties_at_t_min_zero_in_a_coplanar_sheet(renderer, oracle, tables):
+    """camera origin inside a sheet of coplanar triangles, t_min = 0: every ray hits many triangles at
+    t = +-0 exactly and the LAST of them in list order keeps the hit (src/geometry/mod.rs:74-79 accepts
+    equality); the tree must still reach every one of them although closest_so_far equals t_min"""
+    rng = np.random.default_rng(16)
+    s = HittableList()
+    for _ in range(200):
+        s.add(Sphere(tuple(rng.uniform(-5, 5, 3)), float(rng.uniform(0.2, 0.6)), _mat(rng)))
+    for _ in range(300):
+        a = np.array((rng.uniform(-6, 6), 1.0, rng.uniform(-6, 6)))
+        b = a + np.array((rng.uniform(-3, 3), 0.0, rng.uniform(-3, 3)))
+        c = a + np.array((rng.uniform(-3, 3), 0.0, rng.uniform(-3, 3)))
+        s.add(Triangle(tuple(a), tuple(b), tuple(c), _mat(rng)))
+    flat = s.flatten()
+    cam = _cam((0.25, 1.0, 0.5), look_at=(2.0, 0.5, -3.0), fov=60.0)
+    for t_min in (0.0, -0.25):
+        p = [make_params(64, 40, spp=2, t_min=t_min)]
+        orc = render_oracle(oracle, tables, flat, cam, p)
+        gpu = render_gpu(renderer, flat, cam, p)
+        assert_same(gpu, orc, oracle)
+        assert (gpu[1] >= 200).all(), "every ray starts inside some triangle of the sheet"
+
+
 def _null_camera(direction=(0.0, 0.0, 0.0)):
     """every pixel gets the same ray origin (0,0,5) and `direction`"""
     cam = _lib.rt_camera()
