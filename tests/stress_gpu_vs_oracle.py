@@ -2,7 +2,8 @@
 tools/stress_tree_vs_list.py (spheres, triangles, cubes and planes in mixed list order,
 slivers, lattices of touching spheres, coplanar sheets, extents from 0.1 to 1000, cameras
 inside and far outside), at a frame size the oracle traces in a fraction of a second
-(96 x 54, 2 samples), with a random t_min now and then.  Sums, primary ids, packed pixels
+(about 5000 pixels, 1 to 3 samples), with other values of t_min, the depth budget, gamma and the
+band partition now and then.  Sums, primary ids, packed pixels
 and segment counts must be identical.  Not collected by pytest; run by
 tests/test_gpu_tree.py for a few seconds and by hand for longer:
     python tests/stress_gpu_vs_oracle.py [seconds] [seed0]"""
@@ -33,14 +34,18 @@ def main():
         rng = np.random.default_rng(seed0 + k)
         flat, cam = scene(rng)
         t_min = 0.001 if rng.random() < 0.8 else float(rng.choice([-1.0, 0.0, 0.05, 2.0]))
-        p = make_params(96, 54, spp=2, seed=k, t_min=t_min)
+        w, h = [(96, 54), (61, 43), (130, 20), (33, 70)][int(rng.integers(0, 4))]
+        stride = 1 if rng.random() < 0.7 else 3
+        p = make_params(w, h, spp=int(rng.integers(1, 4)), seed=k, t_min=t_min,
+                        max_bounces=10 if rng.random() < 0.6 else int(rng.choice([1, 3, 16])),
+                        gamma=bool(rng.random() < 0.7), band_begin=int(rng.integers(0, stride)), band_stride=stride)
         o_acc, o_ids, o_seg = orc.render(flat, cam, tables, p, threads=threads)
         r.set_scene(flat); r.set_camera(cam); r.begin_frame(p.width, p.height); r.render(p)
         acc, ids, seg, packed = r.read_accum(), r.read_primary_ids(), r.ray_count(), r.read_packed()
         a, b = acc.view(np.uint32), np.ascontiguousarray(o_acc[..., :3]).view(np.uint32)
         nan = np.isnan(acc) & np.isnan(o_acc[..., :3])          # NaN payloads may differ
         same = (np.array_equal(a[~nan], b[~nan]) and np.array_equal(ids, o_ids) and seg == o_seg
-                and np.array_equal(packed, orc.pack(o_acc)))
+                and np.array_equal(packed[o_acc[..., 3] > 0], orc.pack(o_acc)[o_acc[..., 3] > 0]))
         rays += seg
         if not same:
             bad += 1
