@@ -34,12 +34,14 @@ struct DevRun {
     uint32_t mode;        // RUN_*
     uint32_t n_levels;    // RUN_FLAT: 1; RUN_TREE: levels of the tree
     uint32_t top_steps;   // steps of the top level (RUN_FLAT: all steps, an even number)
-    uint32_t order_base;  // DevScene::order + order_base: list position in run -> slot offset
+    uint32_t order_base;  // DevScene::order + order_base: list position in run -> slot offset; RUN_TREE: followed
+                          // by the slot offsets of the n_unbounded primitives the tree does not hold
     uint32_t level_base[DEV_MAX_LEVELS];   // RUN_TREE: float4 offset of each level in tree_rec; RUN_FLAT: [0] = first step
     uint32_t level_aux[DEV_MAX_LEVELS];    // RUN_TREE: boxes at each level; RUN_FLAT: [0] = float bits of 1 - eps
     float reach;          // RUN_TREE: max over bounded balls of |centre| + radius
     float inv_2rho;       // RUN_TREE of spheres: 1 / (2 * smallest |radius|), +inf when that is 0 or for triangles
-    uint32_t pad[6];
+    uint32_t n_unbounded; // RUN_TREE: primitives with non-finite or huge coordinates, tested for every ray
+    uint32_t pad[5];
 };
 
 // The primitive list in device memory.  All arrays are read with wave-uniform

@@ -249,8 +249,9 @@ __device__ __forceinline__ int32_t list_position(const RT_CONST_AS uint32_t *by_
     return id == ID_LATER ? (int32_t)by_slot[slot] : id;
 }
 // Sphere::hit, src/geometry/mod.rs:60-94; `a` is |dir|^2 (:63)
+// (nan_out, where given, is set when the accepted distance is NaN)
 __device__ __forceinline__ void sphere_exact(const SceneView &sc, uint32_t slot, int32_t id, const Ray &ray,
-                                             float a, float t_min, Hit &h, bool &ff_shared) {
+                                             float a, float t_min, Hit &h, bool &ff_shared, bool *nan_out = nullptr) {
     const f4 g = sc.sph_geom[slot];   // cx, cy, cz, radius
     V3 oc = ray.o - mk(g.x, g.y, g.z);
     float half_b = dot(oc, ray.d);
@@ -265,6 +266,7 @@ __device__ __forceinline__ void sphere_exact(const SceneView &sc, uint32_t slot,
     }
     if (root == h.t && list_position(sc.sph_id, slot, id) < list_position(sc.sph_id, h.slot, h.id)) return;
     h.t = root; h.kind = DEV_SPHERE; h.slot = slot; h.id = id;
+    if (nan_out) *nan_out = root != root;
     if (sc.need_ff_shared) {
         V3 p = ray.o + ray.d * root;
         V3 outward = (p - mk(g.x, g.y, g.z)) / g.w;
@@ -279,7 +281,7 @@ __device__ __forceinline__ float min3(float a, float b, float c) { float m = a <
 // bounding-box gate that keeps the f32 barycentric test from accepting points far outside
 // a sliver or an edge-on triangle
 __device__ __forceinline__ void tri_exact(const SceneView &sc, uint32_t slot, int32_t id, const Ray &ray,
-                                          float t_min, Hit &h, bool &ff_shared) {
+                                          float t_min, Hit &h, bool &ff_shared, bool *nan_out = nullptr) {
     const f4 v0 = sc.tris[3 * slot];
     const f4 e1 = sc.tris[3 * slot + 1];
     const f4 e2 = sc.tris[3 * slot + 2];
@@ -314,6 +316,7 @@ __device__ __forceinline__ void tri_exact(const SceneView &sc, uint32_t slot, in
     }
     if (t == h.t && list_position(sc.tri_id, slot, id) < list_position(sc.tri_id, h.slot, h.id)) return;
     h.t = t; h.kind = DEV_TRI; h.slot = slot; h.id = id;
+    if (nan_out) *nan_out = t != t;
     if (sc.need_ff_shared) {
         V3 outward = unit(cross(E1, E2));
         ff_shared = dot(ray.d, outward) < 0.0f;
@@ -581,14 +584,17 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
                 } else {
                     // level 0: the exact test of the primitives this lane could not reject, in
                     // slot order
-                    while (bits != 0u) {
+                    // (a NaN distance ends the walk at once: the next primitive of the step would
+                    // replace it, and it need not be one that follows in the list)
+                    bool got_nan = false;
+                    while (bits != 0u && !got_nan) {
                         const uint32_t k = (uint32_t)__builtin_ctz(bits);
                         bits &= bits - 1u;
                         const uint32_t slot = run.first + 8u * st + k;
                         RTK_COUNT(sc, 4, 1);
                         RTK_COUNT_ANY(sc, 7, 1);
-                        if (KIND == DEV_SPHERE) sphere_exact(sc, slot, ID_LATER, ray, a, t_min, h, ff_shared);
-                        else tri_exact(sc, slot, ID_LATER, ray, t_min, h, ff_shared);
+                        if (KIND == DEV_SPHERE) sphere_exact(sc, slot, ID_LATER, ray, a, t_min, h, ff_shared, &got_nan);
+                        else tri_exact(sc, slot, ID_LATER, ray, t_min, h, ff_shared, &got_nan);
                     }
                     // next pending sibling, of this node or of its nearest ancestor that has one
                     const unsigned long long rest = pend >> (8u * L);
@@ -614,9 +620,9 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
 // sphere is accepted, whatever is held).  Rays that enter with such numbers
 // (non-finite direction or one outside 1e-6 .. 1e6 in length, NaN closest_so_far
 // inherited from an earlier run, huge origins) are kept out of the walk; a lane whose closest_so_far
-// turns NaN during the walk (a primitive with NaN/overflowing coordinates, a
-// triangle whose determinant underflows) drops out of it.  Both kinds then
-// take the run in list order, the second from the state it entered with.
+// turns NaN (a primitive with NaN/overflowing coordinates) drops out of it.  Both kinds then
+// take the run in list order, the second from the state it entered with.  Primitives that
+// cannot be bounded are not in the tree: the run lists them, and every ray tests them first.
 // ----------------------------------------------------------------------
 template <int KIND>
 __device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &run, bool tracing,
@@ -635,7 +641,16 @@ __device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &ru
             tbl.entry_slot[lane] = h.slot;
             tbl.entry_bits[lane] = (uint32_t)(h.kind + 1) | ((uint32_t)h.ff << 8) | ((uint32_t)ff_shared << 9);
         }
-        walk_tree<KIND>(sc, run, walking, tbl, tree_top, lds_from_level, ray, a, t_min, h, ff_shared);
+        // primitives the tree does not hold (non-finite or huge coordinates): every ray tests them
+        const uint32_t n_unbounded = run.hi[10];
+        for (uint32_t k = 0; k < n_unbounded; ++k) {
+            const uint32_t slot = run.first + sc.order[run.order_base + run.count + k];
+            if (walking && h.t == h.t) {
+                if (KIND == DEV_SPHERE) sphere_exact(sc, slot, ID_LATER, ray, a, t_min, h, ff_shared);
+                else tri_exact(sc, slot, ID_LATER, ray, t_min, h, ff_shared);
+            }
+        }
+        walk_tree<KIND>(sc, run, walking && h.t == h.t, tbl, tree_top, lds_from_level, ray, a, t_min, h, ff_shared);
         if (walking && h.id == ID_LATER) h.id = (int32_t)(KIND == DEV_SPHERE ? sc.sph_id[h.slot] : sc.tri_id[h.slot]);
         if (walking && h.t != h.t) {
             const uint32_t bits = tbl.entry_bits[lane];

@@ -43,9 +43,10 @@ float round_down(double v) {
 }
 
 // A ball the kernel's rejection tests cannot speak for: NaN or infinite numbers, or
-// magnitudes at which the tests' intermediates could overflow.  It is stored as centre
-// 0 with an infinite radius (never rejected, nothing non-finite enters the kernel's
-// arithmetic), and so is every ball above it in the tree.
+// magnitudes at which the tests' intermediates could overflow.  The rejection scan never
+// rejects it; a tree does not hold it at all: such primitives are listed with their run and
+// tested for every ray before the walk (Sphere::hit may accept them with a NaN distance
+// whatever the closest hit so far is, which no bounding volume could express).
 const double BALL_RANGE = 1e15;
 const Ball UNBOUNDED = {0.0, 0.0, 0.0, INFINITY};
 bool unbounded(const Ball &b) { return !(std::abs(b.r) < BALL_RANGE); }
@@ -55,9 +56,13 @@ Ball bounded_or_unbounded(const Ball &b) {
     return UNBOUNDED;
 }
 
-// Bounding box of a leaf or node, in double; (-inf, +inf) when unbounded.
+// Bounding box of a leaf or node, in double.  EVERYWHERE marks a primitive that cannot be
+// bounded; NOWHERE is what the tree holds in its place, and any node without bounded
+// primitives below it.
 struct Box { double lo[3], hi[3]; };
 const Box EVERYWHERE = {{-INFINITY, -INFINITY, -INFINITY}, {INFINITY, INFINITY, INFINITY}};
+const Box NOWHERE = {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
+bool nowhere(const Box &b) { return b.lo[0] > b.hi[0]; }
 
 // Gate of the triangle test (rt_hip.h): the bounding box of v0, v0+e1, v0+e2 widened by
 // 2^-7 of its largest extent plus 2^-20 of the largest |coordinate|, every step in
@@ -170,9 +175,13 @@ void append_box_level(std::vector<float4> &out, const std::vector<Box> &boxes) {
         float lo[8][3], hi[8][3];
         for (size_t c = 0; c < 8; ++c)
             for (int ax = 0; ax < 3; ++ax) {
-                const bool have = 8 * st + c < m;   // children past the end are masked out by the kernel
-                lo[c][ax] = have ? round_down(boxes[8 * st + c].lo[ax]) : INFINITY;
-                hi[c][ax] = have ? round_up(boxes[8 * st + c].hi[ax]) : -INFINITY;
+                // children past the end are masked out by the kernel; a box that holds nothing
+                // becomes one far-away point: its three slabs have no thickness, so the interval
+                // the slab test cuts down ends up empty whatever the ray
+                const bool have = 8 * st + c < m;
+                const bool empty = !have || nowhere(boxes[8 * st + c]);
+                lo[c][ax] = empty ? 3.0e38f : round_down(boxes[8 * st + c].lo[ax]);
+                hi[c][ax] = empty ? 3.0e38f : round_up(boxes[8 * st + c].hi[ax]);
             }
         for (int pr = 0; pr < 4; ++pr)
             for (int ax = 0; ax < 3; ++ax)
@@ -190,11 +199,11 @@ void append_box_level(std::vector<float4> &out, const std::vector<Box> &boxes) {
 // the root of a discriminant that is uncertain by kappa |o-c|^2 lies up to
 // sqrt(r^2 + kappa |o-c|^2) from the centre; rho_min, the smallest radius of the run, bounds
 // that) plus the rounding of the slab test itself.  Boxes fit flat or elongated groups
-// (spheres resting on a plane, a terrain mesh) far better than balls do.  A leaf that is
-// unbounded makes every box above it infinite.
+// (spheres resting on a plane, a terrain mesh) far better than balls do.  Leaves given as
+// NOWHERE (primitives that cannot be bounded) take no part.
 void build_tree(HostScene &sc, DevRun &run, const std::vector<Box> &leaf_boxes, double rho_min) {
     for (const Box &b : leaf_boxes) {
-        if (b.lo[0] == -INFINITY) continue;   // unbounded
+        if (nowhere(b)) continue;
         double far2 = 0.0;
         for (int ax = 0; ax < 3; ++ax) {
             const double m = std::max(std::abs(b.lo[ax]), std::abs(b.hi[ax]));
@@ -217,9 +226,9 @@ void build_tree(HostScene &sc, DevRun &run, const std::vector<Box> &leaf_boxes, 
         // one box per step (eight boxes) of this level
         std::vector<Box> up(n_steps);
         for (size_t k = 0; k < n_steps; ++k) {
-            Box bx = {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
+            Box bx = NOWHERE;
             for (size_t c = 8 * k; c < std::min(cur.size(), 8 * k + 8); ++c)
-                for (int ax = 0; ax < 3; ++ax) {
+                for (int ax = 0; ax < 3 && !nowhere(cur[c]); ++ax) {
                     bx.lo[ax] = std::min(bx.lo[ax], cur[c].lo[ax]);
                     bx.hi[ax] = std::max(bx.hi[ax], cur[c].hi[ax]);
                 }
@@ -313,9 +322,11 @@ int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::strin
                 for (uint32_t k = 0; k < count; ++k) {
                     const Ball &b = sorted[k];
                     const double r = std::abs(b.r);
-                    boxes[k] = unbounded(b) ? EVERYWHERE : Box{{b.x - r, b.y - r, b.z - r}, {b.x + r, b.y + r, b.z + r}};
+                    boxes[k] = unbounded(b) ? NOWHERE : Box{{b.x - r, b.y - r, b.z - r}, {b.x + r, b.y + r, b.z + r}};
                     if (!unbounded(b)) rho_min = std::min(rho_min, r);
+                    else sc.order.push_back(k);      // the run's unbounded primitives follow its order table
                 }
+                run.n_unbounded = (uint32_t)(sc.order.size() - run.order_base - count);
                 build_tree(sc, run, boxes, rho_min);
             } else if (run.mode == RUN_FLAT) {
                 std::vector<float4> recs;
@@ -384,7 +395,12 @@ int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::strin
                 sc.tri_id.push_back(id + order[k]);
                 sc.order[run.order_base + order[k]] = k;
             }
-            if (run.mode == RUN_TREE) build_tree(sc, run, sorted, INFINITY);
+            if (run.mode == RUN_TREE) {
+                for (uint32_t k = 0; k < count; ++k)
+                    if (sorted[k].lo[0] == -INFINITY) { sorted[k] = NOWHERE; sc.order.push_back(k); }
+                run.n_unbounded = (uint32_t)(sc.order.size() - run.order_base - count);
+                build_tree(sc, run, sorted, INFINITY);
+            }
         }
         sc.runs.push_back(run);
         id = end;

@@ -6,7 +6,7 @@ inside and far outside), at a frame size the oracle traces in a fraction of a se
 band partition now and then.  Sums, primary ids, packed pixels
 and segment counts must be identical.  Not collected by pytest; run by
 tests/test_gpu_tree.py for a few seconds and by hand for longer:
-    python tests/stress_gpu_vs_oracle.py [seconds] [seed0]"""
+    python tests/stress_gpu_vs_oracle.py [seconds] [seed0] [share of scenes with NaN/inf/huge coordinates]"""
 import os
 import sys
 import time
@@ -20,9 +20,14 @@ from tests import oracle_lib  # noqa: E402
 from tools.stress_tree_vs_list import scene  # noqa: E402
 
 
+POISON = 0.05      # share of scenes that get non-finite or huge coordinates
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    global POISON
+    POISON = float(sys.argv[3]) if len(sys.argv) > 3 else 0.05
     tables = load_tables()
     r = Renderer(0, tables)
     orc = oracle_lib.load()
@@ -33,6 +38,14 @@ def main():
     while time.time() - t0 < budget:
         rng = np.random.default_rng(seed0 + k)
         flat, cam = scene(rng)
+        if rng.random() < POISON:
+            # a few primitives with NaN, infinite or huge coordinates (they hit every ray with a NaN
+            # distance, or none, whatever the reference's arithmetic yields)
+            a = flat.arrays
+            bad_values = np.array([np.nan, np.inf, -np.inf, 1e19, -3e25, 1e38], dtype=np.float32)
+            for key in ("sph_cx", "sph_r", "tri_v0y", "tri_v1x", "tri_v2z", "cb_cx", "pl_py"):
+                if len(a[key]) and rng.random() < 0.5:
+                    a[key][int(rng.integers(0, len(a[key])))] = bad_values[int(rng.integers(0, len(bad_values)))]
         t_min = 0.001 if rng.random() < 0.8 else float(rng.choice([-1.0, 0.0, 0.05, 2.0]))
         w, h = [(96, 54), (61, 43), (130, 20), (33, 70)][int(rng.integers(0, 4))]
         stride = 1 if rng.random() < 0.7 else 3
