@@ -382,3 +382,28 @@ def test_fuzz_gpu_against_oracle():
     out = subprocess.run([sys.executable, os.path.join(root, "tests", "stress_gpu_vs_oracle.py"), "10", "700000"],
                          capture_output=True, text=True, timeout=200)
     assert out.returncode == 0 and "mismatches 0" in out.stdout.splitlines()[-1], out.stdout[-2000:] + out.stderr[-2000:]
+    # and with NaN, infinite or huge coordinates in every scene
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "stress_gpu_vs_oracle.py"), "8", "4900000", "1.0"],
+                         capture_output=True, text=True, timeout=200)
+    assert out.returncode == 0 and "mismatches 0" in out.stdout.splitlines()[-1], out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_nan_sphere_behind_a_cube_hit_with_negative_t(renderer, oracle, tables):
+    """the camera sits inside a cube that comes first in the list: Cube::hit reports its negative
+    entry distance (src/geometry/mod.rs:158-223), after which no finite root can be accepted
+    (t_min > closest_so_far) - but a sphere with a huge centre still is, with a NaN distance, and then
+    every later sphere the ray's line meets; the tree must not cull on the negative distance"""
+    rng = np.random.default_rng(17)
+    s = HittableList()
+    s.add(Cube((0.0, 0.0, 0.0), 30.0, 30.0, 30.0, Lambertian((0.4, 0.5, 0.6))))
+    c = rng.uniform(-6, 6, (400, 3)).astype(f32)
+    r = rng.uniform(0.2, 0.8, 400).astype(f32)
+    for k in range(400):
+        s.add(Sphere(tuple(c[k]), float(r[k]), _mat(rng)))
+    flat = s.flatten()
+    a = flat.arrays
+    a["sph_cx"][250] = 1e38           # |o - c|^2 overflows: discriminant inf - inf
+    a["sph_r"][120] = np.nan
+    for cam in (_cam((1.0, 2.0, 9.0)), _cam((0.2, 0.1, 0.3), look_at=(3.0, 1.0, -2.0), fov=80.0)):
+        p = [make_params(72, 48, spp=2)]
+        _same_with_nans(render_gpu(renderer, flat, cam, p), render_oracle(oracle, tables, flat, cam, p), oracle)
