@@ -46,6 +46,19 @@ def main():
             for key in ("sph_cx", "sph_r", "tri_v0y", "tri_v1x", "tri_v2z", "cb_cx", "pl_py"):
                 if len(a[key]) and rng.random() < 0.5:
                     a[key][int(rng.integers(0, len(a[key])))] = bad_values[int(rng.integers(0, len(bad_values)))]
+        if rng.random() < 0.06:
+            # directions of extreme length, or an origin so far away that |o|^2 overflows: such rays
+            # bypass every conservative test and take the list as the reference does
+            c = cam.struct
+            scale = float(rng.choice([1e-25, 1e-9, 1e8, 1e20, 1.0]))
+            shift = float(rng.choice([0.0, 0.0, 1e17, 3e19, 1e30]))
+            o = np.array(c.origin[:], dtype=np.float32)
+            llc = np.array(c.lower_left_corner[:], dtype=np.float32)
+            o2 = (o + np.float32(shift)).astype(np.float32)
+            c.lower_left_corner[:] = [float(x) for x in (o2 + (llc - o) * np.float32(scale)).astype(np.float32)]
+            c.origin[:] = [float(x) for x in o2]
+            c.horizontal[:] = [float(np.float32(x) * np.float32(scale)) for x in c.horizontal[:]]
+            c.vertical[:] = [float(np.float32(x) * np.float32(scale)) for x in c.vertical[:]]
         t_min = 0.001 if rng.random() < 0.8 else float(rng.choice([-1.0, 0.0, 0.05, 2.0]))
         w, h = [(96, 54), (61, 43), (130, 20), (33, 70)][int(rng.integers(0, 4))]
         stride = 1 if rng.random() < 0.7 else 3

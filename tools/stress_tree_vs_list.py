@@ -14,8 +14,8 @@ from raytracing_amd import Camera, Renderer, flat_scene_from_arrays, load_tables
 
 def scene(rng):
     style = rng.integers(0, 6)
-    n_s = int(rng.choice([0, 70, 300, 2000]))
-    n_t = int(rng.choice([0, 70, 500, 4000]))
+    n_s = int(rng.choice([0, 40, 70, 300, 2000]))      # 40: the rejection scan of 32..63 spheres
+    n_t = int(rng.choice([0, 40, 70, 500, 4000]))
     if n_s + n_t == 0:
         n_s = 500
     ext = float(10.0 ** rng.uniform(-1, 3))            # scene extent 0.1 .. 1000
