@@ -65,8 +65,21 @@ def main():
         p = make_params(w, h, spp=int(rng.integers(1, 4)), seed=k, t_min=t_min,
                         max_bounces=10 if rng.random() < 0.6 else int(rng.choice([1, 3, 16])),
                         gamma=bool(rng.random() < 0.7), band_begin=int(rng.integers(0, stride)), band_stride=stride)
-        o_acc, o_ids, o_seg = orc.render(flat, cam, tables, p, threads=threads)
-        r.set_scene(flat); r.set_camera(cam); r.begin_frame(p.width, p.height); r.render(p)
+        # one call, or the sample range in two calls (progressive rendering adds into the same sums)
+        calls = [p]
+        if p.spp > 1 and rng.random() < 0.25:
+            cut = int(rng.integers(1, p.spp))
+            calls = [make_params(w, h, spp=p.spp, seed=k, t_min=t_min, max_bounces=p.max_bounces, gamma=bool(p.gamma),
+                                 band_begin=p.band_begin, band_stride=p.band_stride, sample_begin=b, sample_count=c)
+                     for b, c in ((0, cut), (cut, p.spp - cut))]
+        o_acc, o_ids, o_seg = None, None, 0
+        for q in calls:
+            o_acc, ids_q, seg_q = orc.render(flat, cam, tables, q, threads=threads, accum=o_acc)
+            o_ids = ids_q if o_ids is None else o_ids
+            o_seg += seg_q
+        r.set_scene(flat); r.set_camera(cam); r.begin_frame(p.width, p.height)
+        for q in calls:
+            r.render(q)
         acc, ids, seg, packed = r.read_accum(), r.read_primary_ids(), r.ray_count(), r.read_packed()
         a, b = acc.view(np.uint32), np.ascontiguousarray(o_acc[..., :3]).view(np.uint32)
         nan = np.isnan(acc) & np.isnan(o_acc[..., :3])          # NaN payloads may differ
