@@ -375,6 +375,8 @@ int rt_ray_count(rt_ctx *ctx, uint64_t *segments) {
 // Instrumentation counters of kernels built with -DRTK_STATS (slot 0 is the
 // segment count; the others stay zero in the shipped build).  Development aid,
 // deliberately not part of rt_hip.h.
+// development aid: the staging buffer (instrumented builds log into it)
+void *rtdbg_samples_ptr(rt_ctx *ctx) { return C(ctx) ? C(ctx)->d_samples : nullptr; }
 int rtdbg_read_counters(rt_ctx *ctx, uint64_t out[8]) {
     Ctx *c = C(ctx);
     if (!c || !out) return RT_E_BADARG;

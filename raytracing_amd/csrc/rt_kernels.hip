@@ -880,6 +880,9 @@ template <int MODES>
 __global__ __launch_bounds__(waves_of(MODES) * 64, RTK_OCC)
 void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_t n_bands, uint32_t unit_px_log2) {
     __shared__ Lds<MODES> lds;
+#ifdef RTK_WAVE_ENDS
+    const unsigned long long t_begin = wall_clock64();
+#endif
     const SceneView sc = view_of(dsc, fr.segments);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (uint32_t k = threadIdx.x; k < 128; k += blockDim.x) lds.disc[k] = fr.tbl_disc[k];
@@ -1112,6 +1115,16 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
         atomicAdd(fr.segments + 4, tm_scan); atomicAdd(fr.segments + 7, tm_rest);
         atomicAdd(fr.segments + 5, tm_done); atomicAdd(fr.segments + 6, tm_fetch);
         atomicAdd(fr.segments + 3, tm_fin);
+    }
+#endif
+#ifdef RTK_WAVE_ENDS
+    // development aid (tools/wave_ends.py): when each wave started and ended, in ticks of the
+    // 100 MHz clock, at the start of the staging buffer (meaningful for launches that do not
+    // render the pixels whose staging area that is, e.g. every 8th band starting with band 1)
+    if (lane == 0) {
+        unsigned long long *log = (unsigned long long *)fr.samples;
+        const uint32_t wid = blockIdx.x * waves_of(MODES) + wave;
+        log[2 * wid] = t_begin; log[2 * wid + 1] = wall_clock64();
     }
 #endif
     if (lane == 0 && n_seg != 0) atomicAdd(fr.segments, (unsigned long long)n_seg);
