@@ -1124,7 +1124,7 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
     if (lane == 0) {
         unsigned long long *log = (unsigned long long *)fr.samples;
         const uint32_t wid = blockIdx.x * waves_of(MODES) + wave;
-        log[2 * wid] = t_begin; log[2 * wid + 1] = wall_clock64();
+        log[2 * wid] = t_begin | ((unsigned long long)n_seg << 40); log[2 * wid + 1] = wall_clock64();
     }
 #endif
     if (lane == 0 && n_seg != 0) atomicAdd(fr.segments, (unsigned long long)n_seg);

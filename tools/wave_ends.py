@@ -21,8 +21,14 @@ buf = (C.c_uint64 * (2 * n))()
 import ctypes
 hip = ctypes.CDLL("libamdhip64.so")
 hip.hipMemcpy(buf, C.c_void_p(ptr), 16 * n, 2)
-t = np.array(buf, dtype=np.uint64).reshape(n, 2).astype(np.float64) * 1e-5   # ms
+raw = np.array(buf, dtype=np.uint64).reshape(n, 2)
+seg = (raw[:, 0] >> np.uint64(40)).astype(np.float64)          # lane-segments the wave traced
+raw[:, 0] &= np.uint64((1 << 40) - 1); raw[:, 1] &= np.uint64((1 << 40) - 1)
+t = raw.astype(np.float64) * 1e-5   # ms
 t0 = t[:, 0].min(); b = t[:, 0] - t0; e = t[:, 1] - t0
 print("%s stride %d: kernel %.2f ms; waves start %.3f .. %.3f ms; end: first %.2f, median %.2f, 90%% %.2f, 99%% %.2f, last %.2f ms"
       % (name, stride, ms, b.min(), b.max(), e.min(), np.median(e), np.percentile(e, 90), np.percentile(e, 99), e.max()))
 print("  waves still running at last-1.0/0.5/0.25/0.1 ms:", [(int((e > e.max() - x).sum())) for x in (1.0, 0.5, 0.25, 0.1)])
+late = e > np.percentile(e, 99)
+print("  lane-segments per wave: all %.0f +- %.0f; the 1 %% that end last %.0f +- %.0f" % (seg.mean(), seg.std(), seg[late].mean(), seg[late].std()))
+print("  correlation of end time with lane-segments: %.2f" % np.corrcoef(e, seg)[0, 1])
