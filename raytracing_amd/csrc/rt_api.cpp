@@ -39,8 +39,8 @@ struct Ctx {
     float4 *d_accum = nullptr;
     uint32_t *d_packed = nullptr;
     int32_t *d_ids = nullptr;
-    float4 *d_samples = nullptr;   // sample_chunk colour planes, see DevFrame::samples
-    uint32_t sample_chunk = 0;     // samples per pixel one launch renders at most
+    StagedRgb *d_stage = nullptr;  // staging ring of the render launches, see DevFrame::stage
+    uint32_t stage_waves = 0;      // wavefronts it has room for
     unsigned long long *d_segments = nullptr;
     uint32_t *d_queue = nullptr;       // two counters used by alternate launches, see DevFrame::queue
     uint32_t launches = 0;             // render launches so far (picks the counter)
@@ -75,8 +75,7 @@ void free_frame(Ctx *c) {
     if (c->d_accum) (void)hipFree(c->d_accum);
     if (c->d_packed) (void)hipFree(c->d_packed);
     if (c->d_ids) (void)hipFree(c->d_ids);
-    if (c->d_samples) (void)hipFree(c->d_samples);
-    c->d_accum = nullptr; c->d_packed = nullptr; c->d_ids = nullptr; c->d_samples = nullptr;
+    c->d_accum = nullptr; c->d_packed = nullptr; c->d_ids = nullptr;
     c->have_frame = false;
     c->W = c->H = 0;
 }
@@ -134,6 +133,9 @@ int rt_create(int device, rt_ctx **out) {
     int cus = 0;
     if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return bail(e, "hipDeviceGetAttribute");
     c->n_cus = cus > 0 ? (uint32_t)cus : 1u;
+    // staging ring: one part per wavefront a launch can have on this device (96 MiB on 256 CUs)
+    c->stage_waves = rtk_resident_waves(c->n_cus);
+    if ((e = hipMalloc(reinterpret_cast<void **>(&c->d_stage), (size_t)c->stage_waves * DEV_STAGE_WAVE_BYTES)) != hipSuccess) return bail(e, "hipMalloc");
     *out = reinterpret_cast<rt_ctx *>(c);
     return RT_OK;
 }
@@ -150,6 +152,7 @@ void rt_destroy(rt_ctx *ctx) {
     if (c->d_screen) (void)hipFree(c->d_screen);
     if (c->d_segments) (void)hipFree(c->d_segments);
     if (c->d_queue) (void)hipFree(c->d_queue);
+    if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -230,8 +233,8 @@ int rt_set_camera(rt_ctx *ctx, const rt_camera *cam) {
 int rt_begin_frame(rt_ctx *ctx, uint32_t width, uint32_t height) {
     Ctx *c = C(ctx);
     if (!c) return RT_E_BADARG;
-    if (width < 2 || height < 2 || width > 65536u || height > 65536u)
-        return fail(c, RT_E_BADARG, "rt_begin_frame: width and height must be in 2..65536");
+    if (width < 2 || height < 2 || width > 65536u || height > 65536u || (uint64_t)width * height > 0xffffffffull)
+        return fail(c, RT_E_BADARG, "rt_begin_frame: width and height must be in 2..65536 and width*height below 2^32");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t n_px = (size_t)width * height;
     if (!c->have_frame || c->W != width || c->H != height) {
@@ -240,10 +243,6 @@ int rt_begin_frame(rt_ctx *ctx, uint32_t width, uint32_t height) {
         HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_accum), n_px * sizeof(float4)));
         HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_packed), n_px * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_ids), n_px * sizeof(int32_t)));
-        // staging planes for the colours of one launch: up to DEV_SAMPLE_CHUNK samples per pixel,
-        // fewer for frames so large that this would take more than DEV_SAMPLE_BYTES
-        c->sample_chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(DEV_SAMPLE_CHUNK, DEV_SAMPLE_BYTES / (n_px * sizeof(float4))));
-        HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_samples), n_px * c->sample_chunk * sizeof(float4)));
         c->W = width; c->H = height;
         c->have_frame = true;
     }
@@ -254,43 +253,66 @@ int rt_begin_frame(rt_ctx *ctx, uint32_t width, uint32_t height) {
     return RT_OK;
 }
 
+// argument checks of rt_render
+static int check_render(Ctx *c, const rt_params *p, const char *who) {
+    const std::string w(who);
+    if (!p) return fail(c, RT_E_BADARG, w + ": params is null");
+    if (p->band_stride == 0 || p->band_begin >= p->band_stride)
+        return fail(c, RT_E_BADARG, w + ": need band_begin < band_stride");
+    if (p->max_bounces > RT_MAX_BOUNCES) return fail(c, RT_E_BADARG, w + ": max_bounces above RT_MAX_BOUNCES");
+    if ((uint64_t)p->sample_begin + p->sample_count > p->spp)
+        return fail(c, RT_E_BADARG, w + ": sample range exceeds spp");
+    if (p->sampling_mode != RT_SAMPLING_DET) return fail(c, RT_E_BADARG, w + ": unknown sampling_mode");
+    if (!(p->t_min == p->t_min)) return fail(c, RT_E_BADARG, w + ": t_min is NaN");
+    return RT_OK;
+}
+
+// One launch per DEV_SAMPLE_CHUNK samples: the colours of a launch's samples are staged in the
+// ring behind fr.stage until their pixel's work unit is complete.  `clear` (may be null): bytes
+// zeroed on the stream before every launch (the queue counters of a scratch that other calls
+// share); otherwise the two counters behind `queue` alternate and the running launch zeroes
+// the other one.
+static int enqueue_render(Ctx *c, const rt_params *p, DevFrame fr, uint32_t stage_waves, uint32_t *queue,
+                          void *clear, size_t clear_bytes) {
+    const uint32_t n_bands = bands_of(p->height, p->band_begin, p->band_stride);
+    if (n_bands == 0 || p->sample_count == 0) return RT_OK;
+    rt_params part = *p;
+    // development aid: RT_HIP_UNIT_PX=2|4|8|16|32|64 fixes the pixels of a tile per work unit
+    // (default: by launch size, see rtk_launch_render); a unit's samples must fit a ring slot
+    const char *up = std::getenv("RT_HIP_UNIT_PX");
+    int unit_px_log2 = -1;
+    for (int k = 1; up && k <= 6; ++k) if (std::atoi(up) == (1 << k)) unit_px_log2 = k;
+    uint32_t chunk = DEV_SAMPLE_CHUNK;
+    if (unit_px_log2 > 0) chunk = std::min<uint32_t>(chunk, (1u << DEV_STAGE_ITEM_BITS) >> unit_px_log2);
+    for (uint32_t done = 0; done < p->sample_count; done += chunk) {
+        part.sample_begin = p->sample_begin + done;
+        part.sample_count = std::min(chunk, p->sample_count - done);
+        if (clear) {
+            HIP_TRY(c, hipMemsetAsync(clear, 0, clear_bytes, c->stream));
+            fr.queue = queue; fr.queue_next = queue + 1;
+        } else {
+            fr.queue = queue + (c->launches & 1u);
+            fr.queue_next = queue + ((c->launches + 1u) & 1u);
+        }
+        HIP_TRY(c, rtk_launch_render(c->dsc, c->cam, part, fr, n_bands, c->n_cus, stage_waves, unit_px_log2, c->stream));
+        if (!clear) c->launches += 1u;     // only a launch that ran has zeroed the other counter
+    }
+    return RT_OK;
+}
+
 int rt_render(rt_ctx *ctx, const rt_params *p) {
     Ctx *c = C(ctx);
     if (!c) return RT_E_BADARG;
-    if (!p) return fail(c, RT_E_BADARG, "rt_render: params is null");
+    int rc = check_render(c, p, "rt_render");
+    if (rc != RT_OK) return rc;
     if (!c->have_tables || !c->have_scene || !c->have_cam || !c->have_frame)
         return fail(c, RT_E_STATE, "rt_render: tables, scene, camera and frame must be set first");
     if (p->width != c->W || p->height != c->H)
         return fail(c, RT_E_BADARG, "rt_render: width/height differ from rt_begin_frame");
-    if (p->band_stride == 0 || p->band_begin >= p->band_stride)
-        return fail(c, RT_E_BADARG, "rt_render: need band_begin < band_stride");
-    if (p->max_bounces > RT_MAX_BOUNCES) return fail(c, RT_E_BADARG, "rt_render: max_bounces above RT_MAX_BOUNCES");
-    if ((uint64_t)p->sample_begin + p->sample_count > p->spp)
-        return fail(c, RT_E_BADARG, "rt_render: sample range exceeds spp");
-    if (p->sampling_mode != RT_SAMPLING_DET) return fail(c, RT_E_BADARG, "rt_render: unknown sampling_mode");
-    if (!(p->t_min == p->t_min)) return fail(c, RT_E_BADARG, "rt_render: t_min is NaN");
-    const uint32_t n_bands = bands_of(p->height, p->band_begin, p->band_stride);
-    if (n_bands == 0 || p->sample_count == 0) return RT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    DevFrame fr{c->d_disc, c->d_sphere, c->d_screen, c->d_accum, c->d_ids, c->d_samples, c->d_segments,
+    DevFrame fr{c->d_disc, c->d_sphere, c->d_screen, c->d_accum, c->d_ids, c->d_stage, c->d_segments,
                 nullptr, nullptr};
-    // one launch per sample_chunk samples: the per-sample colours of a launch are staged
-    // in d_samples before they are added to the sums in sample order
-    rt_params part = *p;
-    // development aid: RT_HIP_UNIT_PX=2|4|8|16|32|64 fixes the pixels of a tile per work unit
-    // (default: by launch size, see rtk_launch_render)
-    const char *up = std::getenv("RT_HIP_UNIT_PX");
-    int unit_px_log2 = -1;
-    for (int k = 1; up && k <= 6; ++k) if (std::atoi(up) == (1 << k)) unit_px_log2 = k;
-    for (uint32_t done = 0; done < p->sample_count; done += c->sample_chunk) {
-        part.sample_begin = p->sample_begin + done;
-        part.sample_count = std::min(c->sample_chunk, p->sample_count - done);
-        fr.queue = c->d_queue + (c->launches & 1u);
-        fr.queue_next = c->d_queue + ((c->launches + 1u) & 1u);
-        HIP_TRY(c, rtk_launch_render(c->dsc, c->cam, part, fr, n_bands, c->n_cus, unit_px_log2, c->stream));
-        c->launches += 1u;     // only a launch that ran has zeroed the other counter
-    }
-    return RT_OK;
+    return enqueue_render(c, p, fr, c->stage_waves, c->d_queue, nullptr, 0);
 }
 
 int rt_pack(rt_ctx *ctx) {
@@ -376,7 +398,7 @@ int rt_ray_count(rt_ctx *ctx, uint64_t *segments) {
 // segment count; the others stay zero in the shipped build).  Development aid,
 // deliberately not part of rt_hip.h.
 // development aid: the staging buffer (instrumented builds log into it)
-void *rtdbg_samples_ptr(rt_ctx *ctx) { return C(ctx) ? C(ctx)->d_samples : nullptr; }
+void *rtdbg_stage_ptr(rt_ctx *ctx) { return C(ctx) ? C(ctx)->d_stage : nullptr; }
 int rtdbg_read_counters(rt_ctx *ctx, uint64_t out[8]) {
     Ctx *c = C(ctx);
     if (!c || !out) return RT_E_BADARG;

@@ -70,8 +70,14 @@ struct DevScene {
     uint32_t lds_run, lds_level, lds_first, lds_count;
     uint32_t modes;           // bit 0: some run is RUN_FLAT, bit 1: some run is RUN_TREE
 };
-#define DEV_SAMPLE_CHUNK 64u     // samples per pixel one launch renders at most (sizes DevFrame::samples)
-#define DEV_SAMPLE_BYTES (12ull << 30)   // ... as long as the staging planes stay under 12 GiB
+#define DEV_SAMPLE_CHUNK 64u     // samples per pixel one launch renders at most
+// Staging ring: every wavefront of a render launch keeps the colours of its unfinished work
+// units in a part of its own, DEV_STAGE_SLOTS units of at most 2^DEV_STAGE_ITEM_BITS (pixel,
+// sample) items, 12 bytes each.  The ring's size depends on the launch's grid, not on the frame.
+#define DEV_STAGE_ITEM_BITS 9u
+#define DEV_STAGE_SLOTS 4u
+struct StagedRgb { float r, g, b; };
+#define DEV_STAGE_WAVE_BYTES ((size_t)sizeof(StagedRgb) * DEV_STAGE_SLOTS << DEV_STAGE_ITEM_BITS)   // 24 KiB
 #ifndef DEV_TREE_LDS_F4
 #define DEV_TREE_LDS_F4 2256u     // float4s of tree per workgroup (35 KB): the workgroup's LDS stays under 80 KB
 #endif
@@ -83,15 +89,19 @@ struct DevFrame {
     const float *tbl_screen;  // 16384
     float4 *accum;            // {r,g,b,n} per pixel, display order
     int32_t *primary_ids;     // per pixel, display order
-    float4 *samples;          // colour of sample k of this launch at [k * width*height + pixel]
+    StagedRgb *stage;         // staging ring, DEV_STAGE_WAVE_BYTES per wavefront of the grid
     unsigned long long *segments;
     uint32_t *queue;          // work units of the running launch handed out so far (zero when it starts)
     uint32_t *queue_next;     // the counter the next launch on the stream will use: the running one zeroes it
 };
 
+// stage_waves: wavefronts the staging ring behind fr.stage has room for (the grid is cut to it);
+// unit_px_log2: pixels of a tile per work unit, or -1 to choose by launch size
 hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_params &p,
-                             const DevFrame &fr, uint32_t n_bands, uint32_t n_cus, int unit_px_log2,
-                             hipStream_t stream);
+                             const DevFrame &fr, uint32_t n_bands, uint32_t n_cus, uint32_t stage_waves,
+                             int unit_px_log2, hipStream_t stream);
+// wavefronts a render launch puts on a device with n_cus compute units at most
+uint32_t rtk_resident_waves(uint32_t n_cus);
 hipError_t rtk_launch_pack_bands(const float4 *accum, uint32_t *out, uint32_t W, uint32_t H,
                                  uint32_t band_begin, uint32_t band_stride, uint32_t n_bands,
                                  hipStream_t stream);

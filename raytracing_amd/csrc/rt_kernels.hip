@@ -29,6 +29,7 @@
 #ifndef RTK_SUM_BATCH
 #define RTK_SUM_BATCH 16u    // staged colours fetched at a time when a unit is added up
 #endif
+static_assert(DEV_STAGE_SLOTS == 4u, "UnitRing and the slot arithmetic assume four units in flight per wave");
 #ifndef RTK_TREE_WAVES
 #define RTK_TREE_WAVES 8
 #endif
@@ -861,12 +862,12 @@ __device__ __forceinline__ V3 sky(V3 ud, bool gamma) {
 // to four units in flight per wave, UnitRing).  Pixels differ a lot in segments per sample;
 // with one lane per pixel a wave would wait for its slowest pixel.
 //
-// The colour of every sample goes to fr.samples.  When the last item of a unit is finished
+// The colour of every sample goes to the wave's part of the staging ring (fr.stage).  When the last item of a unit is finished
 // the wave adds the unit's samples to the pixel sums IN SAMPLE ORDER: `px_colour += ...`
 // (src/raytracer.rs:262) is an ordered f32 sum and must not depend on which lane finished
 // first.  Nothing is shared between waves.
 // ----------------------------------------------------------------------
-constexpr uint32_t ITEM_BITS = 12;   // item index inside a unit: at most 64 pixels x 64 samples
+constexpr uint32_t ITEM_BITS = DEV_STAGE_ITEM_BITS;   // item index inside a unit: pixels of the unit x samples of the launch <= 512
 
 template <int MODES>
 #ifndef RTK_OCC
@@ -897,8 +898,10 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
 
     const uint32_t W = p.width, H = p.height;
     const bool gamma = p.gamma != 0;
-    const size_t n_px = (size_t)W * H;
     UnitRing &ring = lds.ring[wave];
+    // this wave's part of the staging ring: DEV_STAGE_SLOTS units of up to 2^ITEM_BITS colours;
+    // an item's place is its own number, ring slot << ITEM_BITS | index in the unit
+    StagedRgb *const stage = fr.stage + ((size_t)(blockIdx.x * waves_of(MODES) + wave) << (ITEM_BITS + 2u));
 
     // units of this launch: tile by tile along the band, the parts of a tile one after the other
     const uint32_t tiles_x = (W + TILE - 1u) / TILE;
@@ -957,26 +960,28 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
     auto finish_unit = [&](uint32_t slot) {
         const uint32_t xy = ring.xy[slot];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // the unit's pixel number `lane` (see where()): column lane % 8, row lane / 8
         const uint32_t pi = (xy & 0xffffu) + (lane & 7u), pj = (xy >> 16) + (lane >> 3);
-        if ((lane & 7u) < unit_cols && (lane >> 3) < unit_rows && pi < W && pj < H) {
+        if (lane < unit_px && pi < W && pj < H) {
             const size_t pix_out = (size_t)(H - 1u - pj) * W + pi;   // src/raytracer.rs:265
             float4 acc = fr.accum[pix_out];
             V3 px = mk(acc.x, acc.y, acc.z);
             // with a depth budget of 0 every sample is black and nothing was traced
             const uint32_t n_add = p.max_bounces > 0 ? p.sample_count : 0u;
-            const float4 *src = fr.samples + pix_out;
+            // sample k of the unit's pixel `lane` is item lane + pixels of the unit * k
+            const StagedRgb *src = stage + ((slot << ITEM_BITS) | lane);
             uint32_t k = 0;
             // RTK_SUM_BATCH loads on the way at a time; the additions keep their order (src/raytracer.rs:262)
             for (; k + RTK_SUM_BATCH <= n_add; k += RTK_SUM_BATCH) {
-                float4 c[RTK_SUM_BATCH];
+                StagedRgb c[RTK_SUM_BATCH];
 #pragma unroll
-                for (uint32_t m = 0; m < RTK_SUM_BATCH; ++m) c[m] = src[(size_t)(k + m) * n_px];
+                for (uint32_t m = 0; m < RTK_SUM_BATCH; ++m) c[m] = src[(size_t)(k + m) << unit_px_log2];
 #pragma unroll
-                for (uint32_t m = 0; m < RTK_SUM_BATCH; ++m) px = px + mk(c[m].x, c[m].y, c[m].z);
+                for (uint32_t m = 0; m < RTK_SUM_BATCH; ++m) px = px + mk(c[m].r, c[m].g, c[m].b);
             }
             for (; k < n_add; ++k) {
-                const float4 c = src[(size_t)k * n_px];
-                px = px + mk(c.x, c.y, c.z);
+                const StagedRgb c = src[(size_t)k << unit_px_log2];
+                px = px + mk(c.r, c.g, c.b);
             }
             fr.accum[pix_out] = make_float4(px.x, px.y, px.z, acc.w + (float)p.sample_count);
         }
@@ -1078,7 +1083,8 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
                     if (k >= 4u) c = mk(a3.x, a3.y, a3.z) * c;
                     k = k >= 4u ? k - 4u : 0u;
                 }
-                fr.samples[(size_t)(at.s - p.sample_begin) * n_px + pix_out] = make_float4(c.x, c.y, c.z, 0.0f);
+                StagedRgb out; out.r = c.x; out.g = c.y; out.b = c.z;
+                stage[item] = out;
                 alive = false;
             }
 #ifdef RTK_TIMES
@@ -1119,12 +1125,10 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
 #endif
 #ifdef RTK_WAVE_ENDS
     // development aid (tools/wave_ends.py): when each wave started and ended, in ticks of the
-    // 100 MHz clock, at the start of the staging buffer (meaningful for launches that do not
-    // render the pixels whose staging area that is, e.g. every 8th band starting with band 1)
+    // 100 MHz clock, at the start of the wave's part of the staging ring (free by now)
     if (lane == 0) {
-        unsigned long long *log = (unsigned long long *)fr.samples;
-        const uint32_t wid = blockIdx.x * waves_of(MODES) + wave;
-        log[2 * wid] = t_begin | ((unsigned long long)n_seg << 40); log[2 * wid + 1] = wall_clock64();
+        unsigned long long *log = (unsigned long long *)stage;
+        log[0] = t_begin | ((unsigned long long)n_seg << 40); log[1] = wall_clock64();
     }
 #endif
     if (lane == 0 && n_seg != 0) atomicAdd(fr.segments, (unsigned long long)n_seg);
@@ -1179,14 +1183,17 @@ hipError_t rtk_launch_pack_bands(const float4 *accum, uint32_t *out, uint32_t W,
                        n_bands);
     return hipGetLastError();
 }
+uint32_t rtk_resident_waves(uint32_t n_cus) { return n_cus * 4u * RTK_OCC; }
 hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_params &p,
-                             const DevFrame &fr, uint32_t n_bands, uint32_t n_cus, int unit_px_log2,
-                             hipStream_t stream) {
+                             const DevFrame &fr, uint32_t n_bands, uint32_t n_cus, uint32_t stage_waves,
+                             int unit_px_log2, hipStream_t stream) {
     const uint32_t waves = (uint32_t)rtk::waves_of((int)(sc.modes & 3u));
     const uint32_t tiles_x = (p.width + rtk::TILE - 1u) / rtk::TILE;
     const uint64_t n_tiles = (uint64_t)tiles_x * n_bands;
-    const uint64_t resident = (uint64_t)n_cus * (4u * RTK_OCC / waves);   // workgroups the chip holds at once
-    if (p.sample_count > 64u || p.width > 65536u || p.height > 65536u) return hipErrorInvalidValue;
+    // workgroups the chip holds at once, and the staging ring has room for
+    const uint64_t resident = std::min<uint64_t>((uint64_t)n_cus * (4u * RTK_OCC / waves), stage_waves / waves);
+    if (p.sample_count > DEV_SAMPLE_CHUNK || p.width > 65536u || p.height > 65536u || resident == 0u) return hipErrorInvalidValue;
+    const uint64_t max_items = 1ull << DEV_STAGE_ITEM_BITS;    // a unit's colours must fit one ring slot
     // Pixels of a tile per work unit (part of a row, or whole rows): the fewest that still give a
     // unit 512 work items (eight per lane).  Measured on 4K frames at 64 samples per launch, whole
     // frame / one eighth of the bands, 10,000 spheres: 4 pixels 135.2 / 17.4 ms, 8 pixels 132.2 /
@@ -1194,12 +1201,13 @@ hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_
     // million-triangle scene 69.8 / 9.2 ms with 4, 64.9 / 9.4 with 8, 75.9 / 22.1 with 64.
     if (unit_px_log2 < 1 || unit_px_log2 > 6) {
         unit_px_log2 = 3;
-        while (unit_px_log2 < 6 && ((uint64_t)p.sample_count << unit_px_log2) < 512u) ++unit_px_log2;
+        while (unit_px_log2 < 6 && ((uint64_t)p.sample_count << (unit_px_log2 + 1)) <= max_items) ++unit_px_log2;
         // a small launch (one GPU's share of a frame): half as long units, so that a wave still
         // gets a few dozen of them
         if ((n_tiles << (6 - unit_px_log2)) < 48u * resident * waves && ((uint64_t)p.sample_count << unit_px_log2) >= 512u)
             --unit_px_log2;
     }
+    if (((uint64_t)p.sample_count << unit_px_log2) > max_items) return hipErrorInvalidValue;
     const uint64_t n_units = n_tiles << (6 - unit_px_log2);
     if (n_units >= 0xffffffffull - resident * waves) return hipErrorInvalidValue;
     // as many workgroups as the chip holds, fewer when there are not that many work units

@@ -1,5 +1,5 @@
 """Development aid: when the waves of one render launch start and end (library built with
--DRTK_WAVE_ENDS writes the times into the staging buffer).  usage: wave_ends.py <lib.so> [workload] [stride]"""
+-DRTK_WAVE_ENDS writes the times into the staging ring).  usage: wave_ends.py <lib.so> [workload] [stride]"""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -9,19 +9,20 @@ name = sys.argv[2] if len(sys.argv) > 2 else "c4"
 stride = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 wl = workloads.workload(name); w, h, spp = wl["width"], wl["height"], wl["spp"]
 r = Renderer(0, load_tables()); r.set_scene(wl["flat"]); r.set_camera(wl["camera"]); r.begin_frame(w, h)
-p = make_params(w, h, spp=spp, sample_begin=0, sample_count=64, band_begin=1 % stride, band_stride=stride)   # not band 0: the log sits in its staging area
+p = make_params(w, h, spp=spp, sample_begin=0, sample_count=64, band_begin=1 % stride, band_stride=stride)
 r.render(p); r.sync()
 r.timer_start(); r.render(p); ms = r.timer_stop()
 # the staging buffer's address: read it back through the debug hook of the library
 lib = r._lib
-lib.rtdbg_samples_ptr.restype = C.c_void_p; lib.rtdbg_samples_ptr.argtypes = [C.c_void_p]
-ptr = lib.rtdbg_samples_ptr(r._ctx)
+lib.rtdbg_stage_ptr.restype = C.c_void_p; lib.rtdbg_stage_ptr.argtypes = [C.c_void_p]
+ptr = lib.rtdbg_stage_ptr(r._ctx)
 n = 4096
-buf = (C.c_uint64 * (2 * n))()
+STRIDE = 24576 // 8          # every wave logs at the start of its 24 KiB of the staging ring
+buf = (C.c_uint64 * (STRIDE * n))()
 import ctypes
 hip = ctypes.CDLL("libamdhip64.so")
-hip.hipMemcpy(buf, C.c_void_p(ptr), 16 * n, 2)
-raw = np.array(buf, dtype=np.uint64).reshape(n, 2)
+hip.hipMemcpy(buf, C.c_void_p(ptr), 8 * STRIDE * n, 2)
+raw = np.array(buf, dtype=np.uint64).reshape(n, STRIDE)[:, :2].copy()
 seg = (raw[:, 0] >> np.uint64(40)).astype(np.float64)          # lane-segments the wave traced
 raw[:, 0] &= np.uint64((1 << 40) - 1); raw[:, 1] &= np.uint64((1 << 40) - 1)
 t = raw.astype(np.float64) * 1e-5   # ms
