@@ -155,6 +155,28 @@ int rt_begin_frame(rt_ctx *ctx, uint32_t width, uint32_t height);
  * the per-pixel sums (`px_colour += ray_colour(...)`, src/raytracer.rs:262).
  * Asynchronous on the context's stream. */
 int rt_render(rt_ctx *ctx, const rt_params *params);
+/* rt_render for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in
+ * the reference.  It needs no rt_begin_frame: the caller owns the outputs, in device
+ * memory, and the library's own working memory (the staging ring of unfinished work
+ * units and the queue counters) is a fixed array inside the library's code object,
+ * RT_STATIC_SCRATCH_BYTES per GPU, held from the first rt_create on that GPU until the
+ * process ends.  The call makes no hipMalloc/hipFree.
+ *   accum_device    float4 {r,g,b,n} per pixel, display order, width*height of them;
+ *                   the call ADDS the samples it renders (zero it before sample 0)
+ *   ids_device      int32 per pixel, display order; written for sample 0 only
+ *   segments_device uint64 the segment count is added to, or NULL
+ * Limits: 2..65536 pixels per side and at most RT_STATIC_MAX_PIXELS pixels, anything
+ * larger is RT_E_BADARG; the ring holds RT_STATIC_MAX_WAVES wavefronts (a 256-CU GPU
+ * filled to 16 per CU), a launch is cut to that many on a larger device.  Every call
+ * on one GPU uses that GPU's one array: calls on the same GPU that overlap in time
+ * (two contexts, two host threads) race; calls on one context are ordered by its
+ * stream.  Asynchronous like rt_render; sums are bit-identical to rt_render's. */
+#define RT_STATIC_MAX_WAVES 4096u
+#define RT_STATIC_SCRATCH_BYTES (256u + RT_STATIC_MAX_WAVES * 24576u) /* 96 MiB + 256 B */
+#define RT_STATIC_MAX_PIXELS 0xffffffffu
+int rt_render_static(rt_ctx *ctx, const rt_params *params, void *accum_device,
+                     int32_t *ids_device, uint64_t *segments_device);
 /* enqueue the quantiser write_colour (src/raytracer.rs:46-55) over the whole frame */
 int rt_pack(rt_ctx *ctx);
 int rt_sync(rt_ctx *ctx);

@@ -108,6 +108,10 @@ extern "C" {
     pub fn rt_set_camera(ctx: *mut rt_ctx, cam: *const rt_camera) -> c_int;
     pub fn rt_begin_frame(ctx: *mut rt_ctx, width: u32, height: u32) -> c_int;
     pub fn rt_render(ctx: *mut rt_ctx, params: *const rt_params) -> c_int;
+    /// rt_render on caller-owned device buffers, working memory from the library's fixed
+    /// per-GPU scratch: makes no allocation (for callers under graph capture)
+    pub fn rt_render_static(ctx: *mut rt_ctx, params: *const rt_params, accum_device: *mut c_void,
+                            ids_device: *mut i32, segments_device: *mut u64) -> c_int;
     pub fn rt_pack(ctx: *mut rt_ctx) -> c_int;
     pub fn rt_sync(ctx: *mut rt_ctx) -> c_int;
     pub fn rt_read_accum(ctx: *mut rt_ctx, rgb: *mut f32, n_px: usize) -> c_int;

@@ -80,6 +80,7 @@ SIGNATURES = {
     "rt_set_camera": (C.c_int, [_vp, C.POINTER(rt_camera)]),
     "rt_begin_frame": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
     "rt_render": (C.c_int, [_vp, C.POINTER(rt_params)]),
+    "rt_render_static": (C.c_int, [_vp, C.POINTER(rt_params), _vp, _vp, _vp]),
     "rt_pack": (C.c_int, [_vp]),
     "rt_sync": (C.c_int, [_vp]),
     "rt_read_accum": (C.c_int, [_vp, _fp, C.c_size_t]),

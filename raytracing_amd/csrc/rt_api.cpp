@@ -41,6 +41,7 @@ struct Ctx {
     int32_t *d_ids = nullptr;
     StagedRgb *d_stage = nullptr;  // staging ring of the render launches, see DevFrame::stage
     uint32_t stage_waves = 0;      // wavefronts it has room for
+    RtkStaticScratch fixed{};      // the device's static scratch (rt_render_static)
     unsigned long long *d_segments = nullptr;
     uint32_t *d_queue = nullptr;       // two counters used by alternate launches, see DevFrame::queue
     uint32_t launches = 0;             // render launches so far (picks the counter)
@@ -136,6 +137,8 @@ int rt_create(int device, rt_ctx **out) {
     // staging ring: one part per wavefront a launch can have on this device (96 MiB on 256 CUs)
     c->stage_waves = rtk_resident_waves(c->n_cus);
     if ((e = hipMalloc(reinterpret_cast<void **>(&c->d_stage), (size_t)c->stage_waves * DEV_STAGE_WAVE_BYTES)) != hipSuccess) return bail(e, "hipMalloc");
+    // address of this device's static scratch, resolved once per device
+    if ((e = rtk_static_scratch(device, &c->fixed)) != hipSuccess) return bail(e, "hipGetSymbolAddress(scratch)");
     *out = reinterpret_cast<rt_ctx *>(c);
     return RT_OK;
 }
@@ -253,7 +256,7 @@ int rt_begin_frame(rt_ctx *ctx, uint32_t width, uint32_t height) {
     return RT_OK;
 }
 
-// argument checks of rt_render
+// argument checks shared by rt_render and rt_render_static
 static int check_render(Ctx *c, const rt_params *p, const char *who) {
     const std::string w(who);
     if (!p) return fail(c, RT_E_BADARG, w + ": params is null");
@@ -313,6 +316,25 @@ int rt_render(rt_ctx *ctx, const rt_params *p) {
     DevFrame fr{c->d_disc, c->d_sphere, c->d_screen, c->d_accum, c->d_ids, c->d_stage, c->d_segments,
                 nullptr, nullptr};
     return enqueue_render(c, p, fr, c->stage_waves, c->d_queue, nullptr, 0);
+}
+
+int rt_render_static(rt_ctx *ctx, const rt_params *p, void *accum_device, int32_t *ids_device,
+                     uint64_t *segments_device) {
+    Ctx *c = C(ctx);
+    if (!c) return RT_E_BADARG;
+    int rc = check_render(c, p, "rt_render_static");
+    if (rc != RT_OK) return rc;
+    if (!c->have_tables || !c->have_scene || !c->have_cam)
+        return fail(c, RT_E_STATE, "rt_render_static: tables, scene and camera must be set first");
+    if (!accum_device || !ids_device) return fail(c, RT_E_BADARG, "rt_render_static: accum_device or ids_device is null");
+    if (p->width < 2 || p->height < 2 || p->width > 65536u || p->height > 65536u ||
+        (uint64_t)p->width * p->height > RT_STATIC_MAX_PIXELS)
+        return fail(c, RT_E_BADARG, "rt_render_static: frame outside 2..65536 per side or above RT_STATIC_MAX_PIXELS pixels");
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevFrame fr{c->d_disc, c->d_sphere, c->d_screen, static_cast<float4 *>(accum_device), ids_device,
+                c->fixed.stage, segments_device ? reinterpret_cast<unsigned long long *>(segments_device) : c->fixed.segments,
+                nullptr, nullptr};
+    return enqueue_render(c, p, fr, c->fixed.stage_waves, c->fixed.queue, c->fixed.queue, c->fixed.head_bytes);
 }
 
 int rt_pack(rt_ctx *ctx) {

@@ -100,6 +100,16 @@ struct DevFrame {
 hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_params &p,
                              const DevFrame &fr, uint32_t n_bands, uint32_t n_cus, uint32_t stage_waves,
                              int unit_px_log2, hipStream_t stream);
+// The per-GPU static scratch of rt_render_static (see rt_kernels.hip): device addresses of its
+// parts on `device`, which must be the current device the first time it is asked for.
+struct RtkStaticScratch {
+    uint32_t *queue;                // two counters; head_bytes from `queue` on are cleared before a launch
+    unsigned long long *segments;   // sink for the segment count when the caller wants none
+    StagedRgb *stage;
+    uint32_t stage_waves;
+    uint32_t head_bytes;
+};
+hipError_t rtk_static_scratch(int device, RtkStaticScratch *out);
 // wavefronts a render launch puts on a device with n_cus compute units at most
 uint32_t rtk_resident_waves(uint32_t n_cus);
 hipError_t rtk_launch_pack_bands(const float4 *accum, uint32_t *out, uint32_t W, uint32_t H,

@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <mutex>
 
 #include "rt_device.h"
 
@@ -1173,6 +1174,44 @@ void pack_bands(const float4 *__restrict__ accum, uint32_t *__restrict__ out, ui
 }
 
 }  // namespace rtk
+
+// ------------------------------------------------------------ static scratch
+// Staging ring and queue counters of rt_render_static, the entry point for callers that
+// cannot allocate: one array per GPU in the code object's own device memory, 96 MiB + 256 B,
+// held from the first use of the library on that GPU until the process ends.  Bytes 0..7: the
+// two queue counters, 64..71: segment count sink, from 256: the ring (DEV_STAGE_WAVE_BYTES
+// for each of RTK_STATIC_WAVES wavefronts).  In host code the array's name is only a handle:
+// its address on a device comes from hipGetSymbolAddress, once per device.
+#define RTK_STATIC_WAVES RT_STATIC_MAX_WAVES
+#define RTK_STATIC_HEAD 256u
+static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
+static_assert(RT_STATIC_SCRATCH_BYTES == RTK_STATIC_HEAD + (size_t)RTK_STATIC_WAVES * DEV_STAGE_WAVE_BYTES,
+              "rt_hip.h states the size of the static scratch");
+
+hipError_t rtk_static_scratch(int device, RtkStaticScratch *out) {
+    constexpr int MAX_DEVICES = 64;
+    static std::mutex guard;
+    static unsigned char *base[MAX_DEVICES] = {};
+    if (device < 0 || device >= MAX_DEVICES || !out) return hipErrorInvalidValue;
+    std::lock_guard<std::mutex> lock(guard);
+    if (!base[device]) {
+        int current = -1;
+        hipError_t e = hipGetDevice(&current);
+        if (e != hipSuccess) return e;
+        if (current != device) return hipErrorInvalidDevice;   // the symbol resolves on the current device
+        void *ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!ptr) return hipErrorInvalidSymbol;
+        base[device] = static_cast<unsigned char *>(ptr);
+    }
+    out->queue = reinterpret_cast<uint32_t *>(base[device]);
+    out->segments = reinterpret_cast<unsigned long long *>(base[device] + 64);
+    out->stage = reinterpret_cast<StagedRgb *>(base[device] + RTK_STATIC_HEAD);
+    out->stage_waves = RTK_STATIC_WAVES;
+    out->head_bytes = RTK_STATIC_HEAD;
+    return hipSuccess;
+}
 
 // ------------------------------------------------------------ launchers
 hipError_t rtk_launch_pack_bands(const float4 *accum, uint32_t *out, uint32_t W, uint32_t H,

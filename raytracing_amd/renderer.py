@@ -117,6 +117,12 @@ class Renderer:
     def render(self, params):
         self._check(self._lib.rt_render(self._ctx, C.byref(params)))
 
+    def render_static(self, params, accum_ptr, ids_ptr, segments_ptr=None):
+        """rt_render_static: render into caller-owned device buffers (raw device addresses),
+        working memory from the library's fixed per-GPU scratch; allocates nothing"""
+        self._check(self._lib.rt_render_static(self._ctx, C.byref(params), C.c_void_p(accum_ptr),
+                                               C.c_void_p(ids_ptr), C.c_void_p(segments_ptr or 0)))
+
     def pack(self):
         self._check(self._lib.rt_pack(self._ctx))
 
