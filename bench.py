@@ -2,7 +2,11 @@
 """bench.py - throughput of the render loop on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4] [--spp-per-step 64]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+With --gpus N > 1 and no WORLD_SIZE in the environment the script starts its own N ranks
+(one process per GPU, `torch.distributed.run` on 127.0.0.1) before anything touches HIP,
+relays rank 0's JSON line and fails if any rank fails - the stand-in for the reference's
+thread fan-out (src/raytracer.rs:146-171).  Launched under torch.distributed.run it is one rank.
 
 A step is one pass of the hot path over the whole frame: `spp-per-step` samples
 of every pixel, added into the per-pixel sums (the progressive form of
@@ -16,6 +20,15 @@ is exactly two such frames.  The frame is split over the N ranks by interleaved 
 Rank 0 prints ONE JSON line.  `value` is Mrays/s over all ranks, a ray being one
 path segment (one closest-hit query over the list), counted on the device.
 
+`roofline`: the render kernel is bound by VALU issue.  `achieved` is the rate of executed
+VALU lane-operations (one lane of one vector instruction; a fused multiply-add counts once):
+lane-operations per segment from the committed counter pass (profiles/sq_counters.json,
+SQ_INSTS_VALU x SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU of this kernel on this workload)
+x the segments of this run / the kernel time of this run (HIP events).  `peak` is the rate at
+which the chip issues them, 256 CUs x 4 SIMDs x 32 lanes per clock x 2.4 GHz = 78.6 T/s (the
+157.3 TFLOP/s FP32 vector peak counts a fused multiply-add as two).  The work of the reference's
+linear scan that the box tree skips is reported separately (`algorithmic_equivalent`).
+
 Rehearsal of the multi-rank path on a box with one GPU (not a measurement):
 RT_BENCH_REHEARSAL=1 puts every rank on device 0, gathers through gloo and host
 memory instead of RCCL, and has rank 0 render the same samples alone and compare
@@ -24,6 +37,8 @@ the gathered frame with its own, pixel for pixel.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,9 +50,31 @@ import numpy as np  # noqa: E402
 
 # FP32 vector peak of MI355X: 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz, FMA = 2 FLOP
 PEAK_FP32_VECTOR_TFLOPS = 157.3
-# the same issue rate with one flop per instruction: the reference's arithmetic
-# has no fused multiply-add, so a literal evaluation cannot exceed this
-PEAK_FP32_NOFMA_TFLOPS = PEAK_FP32_VECTOR_TFLOPS / 2.0
+# VALU lane-operations per second the chip can issue: 1024 SIMDs x 32 lanes per clock x 2.4 GHz
+# (= the FP32 peak for code without fused multiply-add, which the reference's arithmetic is)
+PEAK_VALU_LANE_TOPS = PEAK_FP32_VECTOR_TFLOPS / 2.0
+METRIC = "Mrays/s (whole node) + ms/frame at 4K 256spp, 1/2/4/8 MI355X"
+
+
+def launch_ranks(args):
+    """Parent of a multi-GPU run: starts one rank per GPU and relays rank 0's line.  Runs before
+    anything initialises HIP in this process, and execs nothing."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    for l in proc.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if proc.returncode != 0 or not lines:
+        sys.exit(proc.returncode or 1)
+    print(lines[-1], flush=True)
+    sys.exit(0)
 
 
 def cpu_baseline(wl, tables, budget_s=15.0):
@@ -74,10 +111,80 @@ def cpu_baseline(wl, tables, budget_s=15.0):
     }
 
 
+def kernel_variant(flat, flat_scan=False):
+    """which instantiation of render_tiles the library picks for this scene"""
+    c = flat.counts
+    tree = (c["n_spheres"] >= 64 or c["n_tris"] >= 64) and not flat_scan
+    rej = 32 <= c["n_spheres"] < 64 or (flat_scan and c["n_spheres"] >= 32)
+    return "render_tiles<%d>" % ((2 if tree else 0) | (1 if rej else 0))
+
+
+def counters_from_profile(key):
+    """Per-segment VALU figures of the render kernel on one workload from the committed rocprofv3
+    --pmc passes (profiles/sq_counters.json, written by tools/collect_counters.py); None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "sq_counters.json")) as f:
+            rec = json.load(f)[key]
+        return rec if rec.get("valu_lane_ops_per_segment") else None
+    except (OSError, ValueError, KeyError, TypeError):
+        return None
+
+
+def hbm_traffic_from_profile(key, spp_per_launch):
+    """HBM bytes per launch of render_tiles from the committed rocprofv3 --pmc passes
+    (profiles/hbm_traffic.json, tools/collect_counters.py); None if absent or taken at another launch size."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            rec = json.load(f)[key]
+        return rec["bytes_per_launch"] if rec.get("spp_per_launch") == spp_per_launch else None
+    except (OSError, ValueError, KeyError, TypeError):
+        return None
+
+
+def valu_roofline(key, kernel, segments_per_launch, kernel_ms, spp_per_launch, flops_seg, flat):
+    """`roofline` object for one kernel launch size: executed VALU lane-operations against the rate
+    the chip issues them (see the module docstring); the counter-derived parts are None when no
+    committed counter pass covers this workload."""
+    prof = counters_from_profile(key)
+    seg_per_s = segments_per_launch / (kernel_ms * 1e-3)
+    out = {"bound": "valu", "achieved": None, "peak": PEAK_VALU_LANE_TOPS, "unit": "TFLOP/s", "frac": None,
+           "traffic": hbm_traffic_from_profile(key, spp_per_launch),
+           "kernel": kernel, "kernel_ms": round(float(kernel_ms), 3),
+           "definition": "achieved = executed VALU lane-operations per second in units of 1e12 (a lane-operation "
+                         "is one lane of one vector instruction = at most one unfused flop; an FMA counts once); "
+                         "peak = 1024 SIMDs x 32 lanes/clk x 2.4 GHz"}
+    if prof is not None:
+        lane_ops = prof["valu_lane_ops_per_segment"] * seg_per_s / 1e12
+        out["achieved"] = round(lane_ops, 3)
+        out["frac"] = round(lane_ops / PEAK_VALU_LANE_TOPS, 4)
+        out["counters"] = {
+            "valu_lane_ops_per_segment": prof["valu_lane_ops_per_segment"],
+            "valu_wave_insts_per_wave_segment": prof["valu_wave_insts_per_wave_segment"],
+            "active_lanes_per_valu_inst": prof["active_lanes_per_valu_inst"],
+            "fma_share_of_valu_insts": prof.get("fma_share_of_valu_insts"),
+            "source": prof.get("source"),
+        }
+        if prof.get("fma_lane_ops_per_segment") is not None:
+            # flops with a fused multiply-add counted twice, against the 157.3 TFLOP/s peak
+            fl = (prof["valu_lane_ops_per_segment"] + prof["fma_lane_ops_per_segment"]) * seg_per_s / 1e12
+            out["frac_of_fp32_peak_fma2"] = round(fl / PEAK_FP32_VECTOR_TFLOPS, 4)
+    c = flat.counts
+    alg = flops_seg * seg_per_s / 1e12
+    out["algorithmic_equivalent"] = {
+        "flops_per_segment": flops_seg, "tflops": round(alg, 3),
+        "of_fp32_peak": round(alg / PEAK_FP32_VECTOR_TFLOPS, 4),
+        "note": "work of the reference's linear scan (18/sphere + 14/plane + 18/cube + 45/triangle + 80 per "
+                "segment, mul/add counted singly) x segments / kernel time; a box tree (scenes with >= 64 spheres "
+                "or triangles) skips most of it, so this is not a utilisation there",
+        "tree": bool(c["n_spheres"] >= 64 or c["n_tris"] >= 64),
+    }
+    return out
+
+
 def flat_scan_probe(r, wl, flops_seg):
     """The same frame through the list-order scan (RT_HIP_FLAT_SCAN=1: every sphere of the
     list is tested for every segment, eight per step through the packed-FMA rejection
-    test, exactly the work the reference's linear scan does): 2 spp, timed with HIP events."""
+    test, exactly the work the reference's linear scan does): 8 spp, timed with HIP events."""
     from raytracing_amd import make_params
     w, h, spp = wl["width"], wl["height"], wl["spp"]
     os.environ["RT_HIP_FLAT_SCAN"] = "1"
@@ -96,48 +203,41 @@ def flat_scan_probe(r, wl, flops_seg):
     r.set_scene(wl["flat"])
     achieved = flops_seg * seg / (ms * 1e-3) / 1e12
     return {"kernel": "render_tiles<1>", "kernel_ms": round(ms, 3), "mrays_per_s": round(seg / ms / 1e3, 3),
-            "achieved": round(achieved, 3), "unit": "TFLOP/s", "peak": PEAK_FP32_VECTOR_TFLOPS,
-            "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4),
-            "frac_of_no_fma_ceiling": round(achieved / PEAK_FP32_NOFMA_TFLOPS, 4),
-            "sample": "8 spp of the full frame, %d segments" % seg}
+            "algorithmic_tflops": round(achieved, 3),
+            "of_fp32_peak": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4),
+            "sample": "8 spp of the full frame, %d segments; every sphere of the list tested for every segment "
+                      "(7 FMAs per sphere in the rejection test)" % seg}
 
 
-def valu_from_profile(workload, segments_per_launch):
-    """VALU figures of render_tiles from the committed rocprofv3 --pmc pass (profiles/sq_counters.json,
-    tools/collect_sq.py): wave instructions per launch and per segment, and rocprof's VALUBusy formula
-    SQ_ACTIVE_INST_VALU * 4 / (SIMDs * busy cycles) with the busy cycles of the same pass
-    (SQ_BUSY_CYCLES is summed over the 32 shader engines, 1024 SIMDs: ACTIVE / (8 * BUSY)); None if absent."""
-    path = os.path.join(ROOT, "profiles", "sq_counters.json")
-    try:
-        with open(path) as f:
-            rec = json.load(f).get(workload)
-        pl = rec["per_launch"]
-        insts, active, busy = pl["SQ_INSTS_VALU"], pl["SQ_ACTIVE_INST_VALU"], pl["SQ_BUSY_CYCLES"]
-    except (OSError, ValueError, KeyError, TypeError):
-        return None
-    return {"wave_insts_per_launch": int(insts), "spp_per_launch": rec.get("spp_per_launch"),
-            "wave_insts_per_wave_segment": round(insts * 64.0 / segments_per_launch, 1),
-            "valu_busy": round(active / (8.0 * busy), 3),
-            "source": "profiles/sq_counters.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES ...)"}
-
-
-def kernel_variant(flat):
-    """which instantiation of render_tiles the library picks for this scene"""
-    c = flat.counts
-    tree = c["n_spheres"] >= 64 or c["n_tris"] >= 64
-    rej = 32 <= c["n_spheres"] < 64
-    return "render_tiles<%d>" % ((2 if tree else 0) | (1 if rej else 0))
-
-
-def hbm_traffic_from_profile(workload):
-    """HBM bytes per launch of render_tiles from the committed rocprofv3 --pmc pass
-    (profiles/hbm_traffic.json, written by tools/collect_traffic.py); None if absent."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f).get(workload, {}).get("bytes_per_launch")
-    except (OSError, ValueError):
-        return None
+def other_workload(name, tables, launches=3):
+    """A short single-GPU measurement of another configuration: `launches` launches of up to 64 spp of
+    the full frame after one warm-up, kernel time from HIP events."""
+    from raytracing_amd import Renderer, make_params, workloads
+    wl = workloads.workload(name)
+    w, h, spp = wl["width"], wl["height"], wl["spp"]
+    sps = min(64, spp)
+    flops_seg = workloads.flops_per_segment(wl["flat"])
+    with Renderer(0, tables) as r:
+        r.set_scene(wl["flat"]); r.set_camera(wl["camera"]); r.begin_frame(w, h)
+        r.render(make_params(w, h, spp=spp, sample_begin=0, sample_count=sps))
+        r.sync()
+        r.begin_frame(w, h)
+        seg0 = r.ray_count()
+        ms = []
+        for k in range(launches):
+            r.timer_start()
+            r.render(make_params(w, h, spp=spp, sample_begin=(k * sps) % max(1, spp - sps + 1), sample_count=sps))
+            ms.append(r.timer_stop())
+        seg = r.ray_count() - seg0
+    kms = float(np.mean(ms))
+    roof = valu_roofline(name, kernel_variant(wl["flat"]), seg / launches, kms, sps, flops_seg, wl["flat"])
+    return {"workload": "%s: %s" % (name, wl["description"]), "spp_per_launch": sps, "kernel_ms": round(kms, 3),
+            "mrays_per_s": round(seg / launches / kms / 1e3, 3),
+            "ms_per_frame": round(kms * spp / sps, 2),
+            "roofline_frac": roof["frac"], "valu_lane_tops": roof["achieved"],
+            "algorithmic_tflops": roof["algorithmic_equivalent"]["tflops"],
+            "algorithmic_of_fp32_peak": roof["algorithmic_equivalent"]["of_fp32_peak"],
+            "hbm_bytes_per_launch": roof["traffic"]}
 
 
 def main():
@@ -149,16 +249,17 @@ def main():
     ap.add_argument("--spp-per-step", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-flat-probe", action="store_true")
+    ap.add_argument("--others", default="c1,c2,c3,c5",
+                    help="other configurations measured briefly on rank 0 of a single-GPU run ('' = none)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
 
     import torch
     import torch.distributed as dist
@@ -183,7 +284,6 @@ def main():
     w, h, spp = wl["width"], wl["height"], wl["spp"]
     sps = max(1, min(args.spp_per_step, spp))
     total_bands = (h + 7) // 8
-    my_bands = len(range(rank, total_bands, world))
     max_bands = len(range(0, total_bands, world))
     flops_seg = workloads.flops_per_segment(wl["flat"])
 
@@ -240,9 +340,9 @@ def main():
                          device="cpu" if rehearsal else "cuda")
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt = float(tmax[0]); seg_total = int(tsum[1]); kern_ms_max = float(tmax[2])
+        dt = float(tmax[0]); seg_total = int(tsum[1])
     else:
-        seg_total = seg; kern_ms_max = float(np.mean(kernel_ms))
+        seg_total = seg
 
     if rehearsal and world > 1 and rank == 0:
         # the same samples on one renderer, all bands: the gathered frame must be identical
@@ -268,11 +368,12 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         paths = w * h * sps * args.steps
-        # roofline of the dominant kernel (render_tiles) on THIS rank: algorithmic
-        # flops of its segments / its mean launch duration (HIP events)
-        achieved = flops_seg * (seg / args.steps) / (np.mean(kernel_ms) * 1e-3) / 1e12
+        # roofline of the dominant kernel (render_tiles) on THIS rank, from its mean launch
+        # duration (HIP events) and its segments per launch
+        roof = valu_roofline(args.workload, kernel_variant(wl["flat"]), seg / args.steps, float(np.mean(kernel_ms)),
+                             sps, flops_seg, wl["flat"])
         out = {
-            "metric": "Mrays/s (whole node) + ms/frame at 4K 256spp, 1/2/4/8 MI355X",
+            "metric": METRIC,
             "value": round(seg_total / dt / 1e6, 3),
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -288,31 +389,23 @@ def main():
                 "ms_per_frame": round(ms_per_step * (spp / sps), 1),
                 "mpaths_per_s": round(paths / dt / 1e6, 3),
                 "segments_per_path": round(seg_total / paths, 4),
+                "segments_per_step": int(round(seg_total / args.steps)),
                 "partition": "interleaved 8-row bands, rank r renders bands r, r+N, ...; "
                              "RCCL all_gather of packed pixels per step" if world > 1 else "single GPU",
                 "sampling": "deterministic schedule (RT_SAMPLING_DET), seed 0",
                 "scan": "implicit 8-ary box tree over each long sphere/triangle run (results identical to the "
                         "reference's list-order scan)",
             },
-            "roofline": {
-                "bound": "valu", "achieved": round(float(achieved), 3), "peak": PEAK_FP32_VECTOR_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(float(achieved) / PEAK_FP32_VECTOR_TFLOPS, 4),
-                "traffic": hbm_traffic_from_profile(args.workload),
-                "kernel": kernel_variant(wl["flat"]), "kernel_ms": round(float(np.mean(kernel_ms)), 3),
-                "flops_per_segment": flops_seg,
-                "note": "achieved = algorithmic flops of the reference's linear scan (18/sphere + 14/plane + "
-                        "18/cube + 45/triangle + 80 per segment, mul/add counted singly) x segments of one launch "
-                        "/ mean launch time (HIP events). The tree skips most of that work, so this exceeds the "
-                        "hardware peak; flat_scan below is the same kernel family testing every sphere of the list "
-                        "for every segment (7 FMAs per sphere in the rejection test instead of the reference's 18 "
-                        "unfused operations, which is why it can pass the unfused ceiling of peak / 2).",
-            },
+            "roofline": roof,
         }
         if flat is not None:
             out["roofline"]["flat_scan"] = flat
-        valu = valu_from_profile(args.workload, seg / args.steps)
-        if valu is not None and valu["spp_per_launch"] == sps:
-            out["roofline"]["valu"] = valu
+        if world == 1 and args.others:
+            r.close()
+            others = []
+            for name in [x.strip() for x in args.others.split(",") if x.strip() and x.strip() != args.workload]:
+                others.append(other_workload(name, tables))
+            out["config"]["others"] = others
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, tables)
         print(json.dumps(out), flush=True)

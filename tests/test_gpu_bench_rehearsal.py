@@ -15,9 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_two_ranks_compose_the_single_gpu_frame():
-    env = dict(os.environ, RT_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+    env = dict(os.environ, RT_BENCH_REHEARSAL="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    # bench.py starts its own ranks when asked for more than one GPU
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "c2", "--spp-per-step", "8"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]

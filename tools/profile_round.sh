@@ -1,21 +1,31 @@
 #!/bin/bash
-# Collects the profiles committed under profiles/ for the default bench workload, in one GPU
-# session: kernel trace + stats of the default bench.py run, then one counter pass each for
-# HBM reads, HBM writes and the SQ instruction counters.  Outputs land in gpurun_out/prof/.
-# usage: tools/profile_round.sh <tag>      (e.g. r01)
+# Collects what is committed under profiles/ in one GPU session:
+#   - kernel trace + stats of the default bench.py run (the line the driver records),
+#   - per workload (default: c4 c2 c5) four counter passes of a short bench.py run: two SQ passes
+#     (issue and lane counters; instruction types), HBM reads, HBM writes.
+# Outputs land in gpurun_out/prof/<workload>/; copy into profiles/ with tools/collect_counters.py.
+# usage: tools/profile_round.sh <tag> [workloads...]      (e.g. r02 c4 c2)
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}; shift
+WLS=${*:-c4 c2 c5}
 OUT=gpurun_out/prof
 mkdir -p $OUT
 export TMPDIR=/tmp
-SHORT="--steps 2 --warmup 1 --no-cpu-baseline --no-flat-probe"
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python3 bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/trace.err || exit 1
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch --output-format csv -- python3 bench.py $SHORT > $OUT/fetch.log 2>&1 || exit 1
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write --output-format csv -- python3 bench.py $SHORT > $OUT/write.log 2>&1 || exit 1
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_VMEM_RD -d $OUT/sq -o sq --output-format csv -- python3 bench.py $SHORT > $OUT/sq.log 2>&1 || exit 1
+timeout -s KILL 400 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python3 bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/trace.err || exit 1
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_default_kernel_stats.csv
-cp $(find $OUT/fetch -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_fetch_size.csv
-cp $(find $OUT/write -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_write_size.csv
-cp $(find $OUT/sq -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_sq.csv
+for W in $WLS; do
+  D=$OUT/$W; mkdir -p $D
+  SHORT="--workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-flat-probe --others="
+  timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SALU SQ_WAIT_INST_ANY -d $D/sq_a -o sq_a --output-format csv -- python3 bench.py $SHORT > $D/bench_sq_a.json 2> $D/sq_a.err || exit 1
+  timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_LDS SQ_INSTS_VMEM_RD -d $D/sq_b -o sq_b --output-format csv -- python3 bench.py $SHORT > $D/bench_sq_b.json 2> $D/sq_b.err || exit 1
+  timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $D/fetch -o fetch --output-format csv -- python3 bench.py $SHORT > $D/bench_fetch.json 2> $D/fetch.err || exit 1
+  timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $D/write -o write --output-format csv -- python3 bench.py $SHORT > $D/bench_write.json 2> $D/write.err || exit 1
+  cp $(find $D/sq_a -name "*counter_collection.csv" | head -1) $D/pmc_sq_a.csv
+  cp $(find $D/sq_b -name "*counter_collection.csv" | head -1) $D/pmc_sq_b.csv
+  cp $(find $D/fetch -name "*counter_collection.csv" | head -1) $D/pmc_fetch_size.csv
+  cp $(find $D/write -name "*counter_collection.csv" | head -1) $D/pmc_write_size.csv
+  rm -rf $D/sq_a $D/sq_b $D/fetch $D/write
+  echo "$W: counter passes done"
+done
 tail -1 $OUT/${TAG}_bench_default.json | cut -c1-300
 cat $OUT/${TAG}_bench_default_kernel_stats.csv
