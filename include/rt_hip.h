@@ -57,9 +57,11 @@ enum { RT_METAL = 0, RT_LAMBERTIAN = 1, RT_DIELECTRIC = 2 };
  *   unit-sphere counter (src/denoising/mod.rs:37-41) starts at a per-path hash
  *   and advances once per closest-hit Metal/Lambertian scatter; the Dielectric
  *   coin (src/geometry/mod.rs:319) is a hash of (path, bounce).
- * RT_SAMPLING_REF_SEQ_PRIMARY is the same schedule under the name that says
- *   what it guarantees: reference-identical primary rays. */
-enum { RT_SAMPLING_DET = 0, RT_SAMPLING_REF_SEQ_PRIMARY = 0 };
+ * It is the only schedule the library renders: the reference's own order of
+ * the secondary draws depends on how its worker threads interleave and on an
+ * OS-seeded generator, so no schedule can reproduce it; any other value of
+ * rt_params.sampling_mode is RT_E_BADARG. */
+enum { RT_SAMPLING_DET = 0 };
 
 #define RT_BAND_ROWS 8u      /* rows per band = tile height of one wavefront */
 #define RT_MAX_BOUNCES 16u   /* the reference uses 10 (src/raytracer.rs:132) */
@@ -209,6 +211,15 @@ int rt_device_buffers(rt_ctx *ctx, void **accum, void **packed, void **ids, void
  * stream. */
 int rt_export_packed_bands(rt_ctx *ctx, uint32_t *dst_device, size_t capacity_px,
                            uint32_t band_begin, uint32_t band_stride);
+/* The fan-in of a multi-GPU frame below any host framework, the receive loop of
+ * src/raytracer.rs:176-185: contexts ctxs[0..n_ctx) (one per GPU, or several on one
+ * GPU) have rendered the same frame size with band_begin = g, band_stride = n_ctx.
+ * Each quantises its own bands into a compact block on its own GPU, the blocks travel
+ * to the GPU of ctxs[0] (one peer-to-peer copy per context, each over its own xGMI
+ * link), are put together there in display order and copied to `out` (host memory,
+ * width*height pixels, 0x00RRGGBB).  Synchronises every context's stream work issued
+ * before the call.  Errors are reported on ctxs[0]. */
+int rt_gather_packed(rt_ctx *const *ctxs, uint32_t n_ctx, uint32_t *out, size_t n_px);
 /* HIP-event stopwatch on the context's stream; stop synchronises */
 int rt_timer_start(rt_ctx *ctx);
 int rt_timer_stop(rt_ctx *ctx, float *milliseconds);

@@ -119,6 +119,8 @@ extern "C" {
     pub fn rt_read_packed(ctx: *mut rt_ctx, out: *mut u32, n_px: usize) -> c_int;
     pub fn rt_read_primary_ids(ctx: *mut rt_ctx, ids: *mut i32, n_px: usize) -> c_int;
     pub fn rt_ray_count(ctx: *mut rt_ctx, segments: *mut u64) -> c_int;
+    /// fan-in of a frame rendered by n_ctx contexts (band_begin = g, band_stride = n_ctx)
+    pub fn rt_gather_packed(ctxs: *const *mut rt_ctx, n_ctx: u32, out: *mut u32, n_px: usize) -> c_int;
     pub fn rt_device_buffers(ctx: *mut rt_ctx, accum: *mut *mut c_void, packed: *mut *mut c_void,
                              ids: *mut *mut c_void, stream: *mut *mut c_void) -> c_int;
     pub fn rt_export_packed_bands(ctx: *mut rt_ctx, dst_device: *mut u32, capacity_px: usize,

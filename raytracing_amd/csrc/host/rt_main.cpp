@@ -9,14 +9,21 @@
 //   rt_main [--width 600] [--spp 1] [--frames 10] [--aperture 0] [--bounces 10]
 //           [--no-gamma] [--seed 0] [--device 0] [--data DIR] [--out PREFIX]
 //           [--obj FILE [--obj-scale S] [--obj-at X Y Z]] [--spheres N] [--chunk N] [--quiet] [--png]
+//           [--gpus G [--same-device]]
 //
 // PREFIX_0000.ppm ... (.png with --png) are written when --out is given.  --chunk N renders the
 // samples of a frame N at a time (progressive); the picture is the same.
+// --gpus G: one context and one host thread per GPU (devices --device .. --device+G-1), context g
+// renders the 8-row bands b with b % G == g - the reference's `(thread_id..height).step_by(
+// num_threads)` (src/raytracer.rs:245) at band height - and rt_gather_packed puts the picture
+// together on the first GPU, like the receive loop (:176-185).  --same-device keeps all G contexts
+// on --device (a rehearsal of the same code on a one-GPU box); the picture is the same either way.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "scene.hpp"
@@ -24,8 +31,9 @@
 namespace {
 
 struct Options {
-    uint32_t width = 600, spp = 1, frames = 10, bounces = 10, seed = 0, chunk = 0, spheres = 0;
+    uint32_t width = 600, spp = 1, frames = 10, bounces = 10, seed = 0, chunk = 0, spheres = 0, gpus = 1;
     int device = 0;
+    bool same_device = false;
     float aperture = 0.f, obj_scale = 1.f;
     rt::vec3 obj_at{0.f, 0.f, 0.f};
     bool gamma = true, quiet = false, png = false;
@@ -37,7 +45,7 @@ struct Options {
     std::fprintf(stderr,
                  "usage: rt_main [--width W] [--spp N] [--frames F] [--aperture A] [--bounces B] [--no-gamma]\n"
                  "               [--seed S] [--device D] [--data DIR] [--out PREFIX] [--chunk N] [--quiet] [--png]\n"
-                 "               [--obj FILE [--obj-scale S] [--obj-at X Y Z]] [--spheres N]\n");
+                 "               [--obj FILE [--obj-scale S] [--obj-at X Y Z]] [--spheres N] [--gpus G [--same-device]]\n");
     std::exit(2);
 }
 
@@ -56,6 +64,8 @@ Options parse(int argc, char** argv) {
         else if (a == "--spheres") { need(i, 1); o.spheres = (uint32_t)std::strtoul(argv[++i], nullptr, 10); }
         else if (a == "--chunk") { need(i, 1); o.chunk = (uint32_t)std::strtoul(argv[++i], nullptr, 10); }
         else if (a == "--device") { need(i, 1); o.device = std::atoi(argv[++i]); }
+        else if (a == "--gpus") { need(i, 1); o.gpus = (uint32_t)std::strtoul(argv[++i], nullptr, 10); }
+        else if (a == "--same-device") o.same_device = true;
         else if (a == "--aperture") { need(i, 1); o.aperture = std::strtof(argv[++i], nullptr); }
         else if (a == "--no-gamma") o.gamma = false;
         else if (a == "--quiet") o.quiet = true;
@@ -72,6 +82,7 @@ Options parse(int argc, char** argv) {
         } else usage(("unknown option " + a).c_str());
     }
     if (o.width < 2 || o.spp == 0) usage("--width must be >= 2 and --spp >= 1");
+    if (o.gpus == 0 || o.gpus > 64) usage("--gpus must be in 1..64");
     return o;
 }
 
@@ -106,54 +117,86 @@ int main(int argc, char** argv) {
             if (!o.quiet) std::printf("INFO: %zu triangles from %s\n", n, o.obj.c_str());
         }
 
-        rt_ctx* ctx = nullptr;
-        check(nullptr, rt_create(o.device, &ctx), "rt_create");
-        check(ctx, rt_upload_tables(ctx, disc.data(), sphere.data(), screen.data()), "rt_upload_tables");
         const rt_scene flat = scene.flatten();
-        check(ctx, rt_upload_scene(ctx, &flat), "rt_upload_scene");
+        // one context per GPU, set up by a host thread of its own (the reference spawns one worker
+        // per core, src/raytracer.rs:146-171)
+        const uint32_t G = o.gpus;
+        std::vector<rt_ctx*> ctx(G, nullptr);
+        std::vector<int> rc(G, RT_OK);
+        std::vector<std::string> failed(G);
+        auto on_every_gpu = [&](auto&& body) {
+            std::vector<std::thread> workers;
+            for (uint32_t g = 0; g < G; ++g) workers.emplace_back([&, g] { body(g); });
+            for (auto& w : workers) w.join();
+            for (uint32_t g = 0; g < G; ++g)
+                if (rc[g] != RT_OK) {
+                    std::fprintf(stderr, "rt_main: GPU %u: %s\n", g, failed[g].c_str());
+                    std::exit(1);
+                }
+        };
+        // the error text is read on the thread that made the call (the text of a failed rt_create is per thread)
+        auto step = [&](uint32_t g, int code, const char* what) {
+            if (rc[g] == RT_OK && code != RT_OK) {
+                rc[g] = code;
+                failed[g] = std::string(what) + " failed (" + std::to_string(code) + "): " + rt_last_error(ctx[g]);
+            }
+            return rc[g] == RT_OK;
+        };
+        on_every_gpu([&](uint32_t g) {
+            const int device = o.same_device ? o.device : o.device + (int)g;
+            step(g, rt_create(device, &ctx[g]), "rt_create") &&
+                step(g, rt_upload_tables(ctx[g], disc.data(), sphere.data(), screen.data()), "rt_upload_tables") &&
+                step(g, rt_upload_scene(ctx[g], &flat), "rt_upload_scene");
+        });
 
         uint64_t total_segments = 0;
         double total_ms = 0.0;
         for (uint32_t frame = 0; frame < o.frames; ++frame) {
             const rt::Camera cam = o.spheres ? rt::random_spheres_camera(o.spp) : world.get_camera(o.aperture, o.spp);
-            check(ctx, rt_set_camera(ctx, &cam.c), "rt_set_camera");
             const auto start_time = std::chrono::steady_clock::now();
-            check(ctx, rt_begin_frame(ctx, image_width, image_height), "rt_begin_frame");
-            rt_params p;
-            std::memset(&p, 0, sizeof p);
-            p.width = image_width; p.height = image_height;
-            p.spp = cam.samples_per_px;
-            p.max_bounces = o.bounces; p.gamma = o.gamma ? 1u : 0u; p.t_min = 0.001f;
-            p.band_begin = 0; p.band_stride = 1;
-            p.sampling_mode = RT_SAMPLING_DET; p.seed = o.seed;
-            const uint32_t chunk = o.chunk ? o.chunk : p.spp;
-            for (uint32_t s = 0; s < p.spp; s += chunk) {
-                p.sample_begin = s;
-                p.sample_count = (p.spp - s < chunk) ? p.spp - s : chunk;
-                check(ctx, rt_render(ctx, &p), "rt_render");
-            }
-            check(ctx, rt_read_packed(ctx, img_buffer.data(), img_buffer.size()), "rt_read_packed");
+            std::vector<uint64_t> segments(G, 0);
+            on_every_gpu([&](uint32_t g) {
+                rt_params p;
+                std::memset(&p, 0, sizeof p);
+                p.width = image_width; p.height = image_height;
+                p.spp = cam.samples_per_px;
+                p.max_bounces = o.bounces; p.gamma = o.gamma ? 1u : 0u; p.t_min = 0.001f;
+                p.band_begin = g; p.band_stride = G;
+                p.sampling_mode = RT_SAMPLING_DET; p.seed = o.seed;
+                if (!step(g, rt_set_camera(ctx[g], &cam.c), "rt_set_camera") ||
+                    !step(g, rt_begin_frame(ctx[g], image_width, image_height), "rt_begin_frame"))
+                    return;
+                const uint32_t chunk = o.chunk ? o.chunk : p.spp;
+                for (uint32_t s = 0; s < p.spp; s += chunk) {
+                    p.sample_begin = s;
+                    p.sample_count = (p.spp - s < chunk) ? p.spp - s : chunk;
+                    if (!step(g, rt_render(ctx[g], &p), "rt_render")) return;
+                }
+                step(g, rt_ray_count(ctx[g], &segments[g]), "rt_ray_count");   // waits for this GPU's share
+            });
+            if (G == 1) check(ctx[0], rt_read_packed(ctx[0], img_buffer.data(), img_buffer.size()), "rt_read_packed");
+            else check(ctx[0], rt_gather_packed(ctx.data(), G, img_buffer.data(), img_buffer.size()), "rt_gather_packed");
             const double ms =
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - start_time).count();
-            uint64_t segments = 0;
-            check(ctx, rt_ray_count(ctx, &segments), "rt_ray_count");
-            total_segments += segments;
+            uint64_t frame_segments = 0;
+            for (uint64_t n : segments) frame_segments += n;
+            total_segments += frame_segments;
             total_ms += ms;
             if (!o.out.empty()) {
                 char name[32];
                 std::snprintf(name, sizeof name, "_%04u.%s", frame, o.png ? "png" : "ppm");
                 const std::string path = o.out + name;
-                if (o.png) check(ctx, rt_write_png(path.c_str(), img_buffer.data(), image_width, image_height), "rt_write_png");
-                else check(ctx, rt_write_ppm(path.c_str(), img_buffer.data(), image_width, image_height), "rt_write_ppm");
+                if (o.png) check(ctx[0], rt_write_png(path.c_str(), img_buffer.data(), image_width, image_height), "rt_write_png");
+                else check(ctx[0], rt_write_ppm(path.c_str(), img_buffer.data(), image_width, image_height), "rt_write_ppm");
             }
             if (!o.quiet)
                 std::printf("frame %u: COUNTER %u, %.3f ms, FPS: %.2f, %.1f Mrays/s\n", frame, world.counter, ms,
-                            1000.0 / ms, (double)segments / ms * 1e-3);
+                            1000.0 / ms, (double)frame_segments / ms * 1e-3);
             world.move_cam();
         }
-        std::printf("{\"frames\": %u, \"width\": %u, \"height\": %u, \"spp\": %u, \"segments\": %llu, \"ms\": %.3f}\n",
-                    o.frames, image_width, image_height, o.spp, (unsigned long long)total_segments, total_ms);
-        rt_destroy(ctx);
+        std::printf("{\"frames\": %u, \"width\": %u, \"height\": %u, \"spp\": %u, \"gpus\": %u, \"segments\": %llu, \"ms\": %.3f}\n",
+                    o.frames, image_width, image_height, o.spp, G, (unsigned long long)total_segments, total_ms);
+        for (rt_ctx* c : ctx) rt_destroy(c);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "rt_main: %s\n", e.what());
         return 1;

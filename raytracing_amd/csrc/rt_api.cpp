@@ -42,6 +42,11 @@ struct Ctx {
     StagedRgb *d_stage = nullptr;  // staging ring of the render launches, see DevFrame::stage
     uint32_t stage_waves = 0;      // wavefronts it has room for
     RtkStaticScratch fixed{};      // the device's static scratch (rt_render_static)
+    uint32_t *d_block = nullptr;   // this context's bands as a compact block (rt_gather_packed)
+    size_t block_px = 0;
+    uint32_t *d_gather = nullptr;  // the blocks of all contexts, on the gathering context's device
+    size_t gather_px = 0;
+    hipEvent_t ev_block = nullptr; // this context's block has arrived in the gather buffer
     unsigned long long *d_segments = nullptr;
     uint32_t *d_queue = nullptr;       // two counters used by alternate launches, see DevFrame::queue
     uint32_t launches = 0;             // render launches so far (picks the counter)
@@ -76,6 +81,9 @@ void free_frame(Ctx *c) {
     if (c->d_accum) (void)hipFree(c->d_accum);
     if (c->d_packed) (void)hipFree(c->d_packed);
     if (c->d_ids) (void)hipFree(c->d_ids);
+    if (c->d_block) (void)hipFree(c->d_block);
+    if (c->d_gather) (void)hipFree(c->d_gather);
+    c->d_block = nullptr; c->d_gather = nullptr; c->block_px = c->gather_px = 0;
     c->d_accum = nullptr; c->d_packed = nullptr; c->d_ids = nullptr;
     c->have_frame = false;
     c->W = c->H = 0;
@@ -124,6 +132,7 @@ int rt_create(int device, rt_ctx **out) {
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&c->ev_block, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipMalloc(reinterpret_cast<void **>(&c->d_disc), 128 * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc(reinterpret_cast<void **>(&c->d_sphere), 768 * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc(reinterpret_cast<void **>(&c->d_screen), 16384 * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc");
@@ -158,6 +167,7 @@ void rt_destroy(rt_ctx *ctx) {
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_block) (void)hipEventDestroy(c->ev_block);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -458,6 +468,63 @@ int rt_export_packed_bands(rt_ctx *ctx, uint32_t *dst_device, size_t capacity_px
     HIP_TRY(c, rtk_launch_pack_bands(c->d_accum, dst_device, c->W, c->H, band_begin, band_stride, n_bands,
                                      c->stream));
     return RT_OK;
+}
+
+int rt_gather_packed(rt_ctx *const *ctxs, uint32_t n_ctx, uint32_t *out, size_t n_px) {
+    if (!ctxs || n_ctx == 0 || !ctxs[0]) return RT_E_BADARG;
+    Ctx *root = C(ctxs[0]);
+    if (!out) return fail(root, RT_E_BADARG, "rt_gather_packed: out is null");
+    if (!root->have_frame) return fail(root, RT_E_STATE, "rt_gather_packed: no frame");
+    const uint32_t W = root->W, H = root->H;
+    if (n_px != (size_t)W * H) return fail(root, RT_E_BADARG, "rt_gather_packed: n_px must be width*height");
+    for (uint32_t g = 0; g < n_ctx; ++g) {
+        Ctx *c = C(ctxs[g]);
+        if (!c || !c->have_frame || c->W != W || c->H != H)
+            return fail(root, RT_E_BADARG, "rt_gather_packed: every context needs a frame of the same size");
+        for (uint32_t k = 0; k < g; ++k)
+            if (ctxs[k] == ctxs[g]) return fail(root, RT_E_BADARG, "rt_gather_packed: a context is listed twice");
+    }
+    // every block is padded to the band count of context 0, the largest
+    const size_t block_px = (size_t)bands_of(H, 0, n_ctx) * RT_BAND_ROWS * W;
+    HIP_TRY(root, hipSetDevice(root->device));
+    if (root->gather_px < block_px * n_ctx) {
+        HIP_TRY(root, hipStreamSynchronize(root->stream));
+        if (root->d_gather) (void)hipFree(root->d_gather);
+        root->d_gather = nullptr; root->gather_px = 0;
+        HIP_TRY(root, hipMalloc(reinterpret_cast<void **>(&root->d_gather), block_px * n_ctx * sizeof(uint32_t)));
+        root->gather_px = block_px * n_ctx;
+    }
+    for (uint32_t g = 0; g < n_ctx; ++g) {
+        Ctx *c = C(ctxs[g]);
+        HIP_TRY(c, hipSetDevice(c->device));
+        uint32_t *dst = root->d_gather + block_px * g;
+        if (c->device == root->device) {
+            // same GPU: quantise straight into the gather buffer
+            if (c != root) HIP_TRY(c, hipStreamWaitEvent(c->stream, root->ev_block, 0));
+            int rc = rt_export_packed_bands(ctxs[g], dst, block_px, g, n_ctx);
+            if (rc != RT_OK) return rc;
+        } else {
+            if (c->block_px < block_px) {
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                if (c->d_block) (void)hipFree(c->d_block);
+                c->d_block = nullptr; c->block_px = 0;
+                HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_block), block_px * sizeof(uint32_t)));
+                c->block_px = block_px;
+            }
+            int rc = rt_export_packed_bands(ctxs[g], c->d_block, block_px, g, n_ctx);
+            if (rc != RT_OK) return rc;
+            // one copy per peer over its own link to the gathering GPU
+            HIP_TRY(c, hipMemcpyPeerAsync(dst, root->device, c->d_block, c->device, block_px * sizeof(uint32_t), c->stream));
+        }
+        if (c != root) HIP_TRY(c, hipEventRecord(c->ev_block, c->stream));
+    }
+    HIP_TRY(root, hipSetDevice(root->device));
+    for (uint32_t g = 1; g < n_ctx; ++g) HIP_TRY(root, hipStreamWaitEvent(root->stream, C(ctxs[g])->ev_block, 0));
+    HIP_TRY(root, rtk_launch_compose_bands(root->d_gather, root->d_packed, W, H, n_ctx, block_px, root->stream));
+    // the next gather's writers wait for this one's reader (contexts that share the root's GPU write
+    // into the gather buffer directly)
+    HIP_TRY(root, hipEventRecord(root->ev_block, root->stream));
+    return read_back(root, out, root->d_packed, n_px * sizeof(uint32_t));
 }
 
 int rt_timer_start(rt_ctx *ctx) {

@@ -116,5 +116,7 @@ hipError_t rtk_launch_pack_bands(const float4 *accum, uint32_t *out, uint32_t W,
                                  uint32_t band_begin, uint32_t band_stride, uint32_t n_bands,
                                  hipStream_t stream);
 hipError_t rtk_launch_pack(const float4 *accum, uint32_t *out, uint32_t n_px, hipStream_t stream);
+hipError_t rtk_launch_compose_bands(const uint32_t *blocks, uint32_t *out, uint32_t W, uint32_t H, uint32_t n_ctx,
+                                    size_t block_px, hipStream_t stream);
 
 #endif

@@ -1173,6 +1173,20 @@ void pack_bands(const float4 *__restrict__ accum, uint32_t *__restrict__ out, ui
     out[(size_t)m * W + x] = v;
 }
 
+// The inverse of pack_bands for a whole node: `blocks` holds the compact blocks of n_ctx
+// contexts one after the other (block_px pixels each; context g rendered the bands
+// b % n_ctx == g); the frame is rebuilt in display order, like the receive loop that fills
+// img_buffer from the workers' messages (src/raytracer.rs:176-185).
+__global__ __launch_bounds__(256)
+void compose_bands(const uint32_t *__restrict__ blocks, uint32_t *__restrict__ out, uint32_t W, uint32_t H,
+                   uint32_t n_ctx, size_t block_px) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = blockIdx.y;                 // row from the bottom
+    if (x >= W || j >= H) return;
+    const uint32_t band = j / TILE, g = band % n_ctx, m = (band / n_ctx) * TILE + (j % TILE);
+    out[(size_t)(H - 1u - j) * W + x] = blocks[(size_t)g * block_px + (size_t)m * W + x];
+}
+
 }  // namespace rtk
 
 // ------------------------------------------------------------ static scratch
@@ -1259,6 +1273,12 @@ hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_
     case 2: hipLaunchKernelGGL(rtk::render_tiles<2>, grid, block, 0, stream, sc, cam, p, fr, n_bands, r); break;
     default: hipLaunchKernelGGL(rtk::render_tiles<3>, grid, block, 0, stream, sc, cam, p, fr, n_bands, r); break;
     }
+    return hipGetLastError();
+}
+hipError_t rtk_launch_compose_bands(const uint32_t *blocks, uint32_t *out, uint32_t W, uint32_t H, uint32_t n_ctx,
+                                    size_t block_px, hipStream_t stream) {
+    dim3 grid((W + 255u) / 256u, H, 1), block(256, 1, 1);
+    hipLaunchKernelGGL(rtk::compose_bands, grid, block, 0, stream, blocks, out, W, H, n_ctx, block_px);
     return hipGetLastError();
 }
 hipError_t rtk_launch_pack(const float4 *accum, uint32_t *out, uint32_t n_px, hipStream_t stream) {

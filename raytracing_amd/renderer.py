@@ -179,6 +179,17 @@ class Renderer:
         return tuple(p.value for p in ptrs)
 
 
+def gather_packed(renderers):
+    """rt_gather_packed: the frame whose bands b % len(renderers) == g renderer g has rendered,
+    put together on the first renderer's GPU; (H, W) uint32 in display order"""
+    first = renderers[0]
+    n = first.width * first.height
+    ctxs = (C.c_void_p * len(renderers))(*[r._ctx for r in renderers])
+    out = np.empty(n, dtype=np.uint32)
+    first._check(first._lib.rt_gather_packed(ctxs, len(renderers), out.ctypes.data_as(C.POINTER(C.c_uint32)), n))
+    return out.reshape(first.height, first.width)
+
+
 def write_ppm(path, packed):
     """PPM::write_file, src/image/mod.rs:61-67"""
     lib = _lib.load()

@@ -142,6 +142,31 @@ def test_every_work_unit_size_gives_the_same_picture(renderer, oracle, tables, u
         assert_same(g, o, oracle)
 
 
+@pytest.mark.parametrize("n_ctx,w,h", [(1, 61, 43), (2, 120, 67), (3, 61, 43), (5, 64, 64), (8, 33, 9)])
+def test_gather_of_several_contexts(renderer, oracle, tables, n_ctx, w, h):
+    """rt_gather_packed: n contexts (here all on GPU 0) render the bands b % n == g of one frame; the
+    library quantises each share, collects the blocks on the first context's GPU and returns the
+    picture in display order.  More contexts than bands (8 on a 9-row frame) leave some with nothing."""
+    from raytracing_amd import Renderer, gather_packed
+    flat = Scene.get_scene().flatten()
+    cam = Scene.get_camera(aperture=0.1)
+    want = render_oracle(oracle, tables, flat, cam, [make_params(w, h, spp=2)])
+    group = [Renderer(0, tables) for _ in range(n_ctx)]
+    try:
+        for rep in range(2):            # the second gather reuses the buffers of the first
+            for g, r in enumerate(group):
+                r.set_scene(flat); r.set_camera(cam); r.begin_frame(w, h)
+                r.render(make_params(w, h, spp=2, band_begin=g, band_stride=n_ctx))
+            got = gather_packed(group)
+            assert np.array_equal(got, oracle.pack(want[0])), rep
+        assert sum(r.ray_count() for r in group) == want[2]
+        with pytest.raises(_lib.RtError):
+            gather_packed(group + [group[0]])        # a context listed twice
+    finally:
+        for r in group:
+            r.close()
+
+
 def test_band_partition(renderer, oracle, tables):
     """the multi-GPU split: bands b % 3 == g rendered separately add up to the frame, and
     rt_export_packed_bands lays each share out as the gather expects"""

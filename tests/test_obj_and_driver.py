@@ -169,6 +169,31 @@ def test_driver_frames_equal_oracle(tmp_path, oracle, tables):
 
 
 @pytest.mark.gpu
+def test_driver_with_several_contexts_equals_one(tmp_path, oracle, tables):
+    """rt_main --gpus 3 --same-device: three contexts (one host thread each) render the interleaved
+    bands and rt_gather_packed puts the frames together - the pictures and segment counts are those
+    of one context, and of the oracle.  On a multi-GPU node the same code runs with one GPU per context."""
+    exe = os.path.join(PKG, "rt_main")
+    w, spp = 200, 2
+    h = image_height(w)
+    outs = {}
+    for gpus, extra in ((1, []), (3, ["--same-device"])):
+        outs[gpus] = subprocess.check_output(
+            [exe, "--width", str(w), "--spp", str(spp), "--frames", "2", "--aperture", "0.1", "--gpus", str(gpus),
+             "--data", os.path.join(PKG, "data"), "--out", str(tmp_path / ("g%d" % gpus)), "--quiet"] + extra,
+            text=True, timeout=100)
+    seg = [o.split('"segments": ')[1].split(",")[0] for o in outs.values()]
+    assert seg[0] == seg[1] and '"gpus": 3' in outs[3]
+    flat = Scene.get_scene().flatten()
+    for frame in range(2):
+        one = _read_ppm(str(tmp_path / ("g1_%04d.ppm" % frame)))
+        three = _read_ppm(str(tmp_path / ("g3_%04d.ppm" % frame)))
+        assert np.array_equal(one, three), frame
+        acc, _, _ = oracle.render(flat, oracle.scene_camera(frame, 0.1), tables, make_params(w, h, spp=spp))
+        assert np.array_equal(three, oracle.pack(acc)), frame
+
+
+@pytest.mark.gpu
 def test_driver_with_obj_mesh_equals_oracle(tmp_path, oracle, tables):
     from raytracing_amd import workloads
     triples = workloads.uv_sphere_mesh(center=(0.0, 0.0, 0.0), radius=1.0, n_lat=12, n_lon=16)
