@@ -220,6 +220,12 @@ int rt_export_packed_bands(rt_ctx *ctx, uint32_t *dst_device, size_t capacity_px
  * width*height pixels, 0x00RRGGBB).  Synchronises every context's stream work issued
  * before the call.  Errors are reported on ctxs[0]. */
 int rt_gather_packed(rt_ctx *const *ctxs, uint32_t n_ctx, uint32_t *out, size_t n_px);
+/* Self-check of the library's arithmetic, no counterpart in the reference: the render
+ * kernel replaces some `/` and sqrt (Rust f32 semantics, src/vector/mod.rs:141-189) by
+ * shorter instruction sequences that must give the same bits for operands of moderate
+ * size.  Runs both on about `operands` random operand sets of that range on the GPU and
+ * returns the number that differ in any bit: mismatches[0] quotients, [1] roots. */
+int rt_check_arith(rt_ctx *ctx, uint64_t operands, uint32_t seed, uint64_t mismatches[2]);
 /* HIP-event stopwatch on the context's stream; stop synchronises */
 int rt_timer_start(rt_ctx *ctx);
 int rt_timer_stop(rt_ctx *ctx, float *milliseconds);

@@ -125,6 +125,8 @@ extern "C" {
                              ids: *mut *mut c_void, stream: *mut *mut c_void) -> c_int;
     pub fn rt_export_packed_bands(ctx: *mut rt_ctx, dst_device: *mut u32, capacity_px: usize,
                                   band_begin: u32, band_stride: u32) -> c_int;
+    /// self-check: short division / square-root sequences against `/` and sqrt on the GPU
+    pub fn rt_check_arith(ctx: *mut rt_ctx, operands: u64, seed: u32, mismatches: *mut u64) -> c_int;
     pub fn rt_timer_start(ctx: *mut rt_ctx) -> c_int;
     pub fn rt_timer_stop(ctx: *mut rt_ctx, milliseconds: *mut f32) -> c_int;
     pub fn rt_camera_new(v_fov_deg: f32, aspect_ratio: f32, aperture: f32, focus_dist: f32,

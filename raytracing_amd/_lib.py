@@ -91,6 +91,7 @@ SIGNATURES = {
     "rt_device_buffers": (C.c_int, [_vp, _vpp, _vpp, _vpp, _vpp]),
     "rt_export_packed_bands": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_uint32]),
     "rt_gather_packed": (C.c_int, [_vpp, C.c_uint32, _up, C.c_size_t]),
+    "rt_check_arith": (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]),
     "rt_timer_start": (C.c_int, [_vp]),
     "rt_timer_stop": (C.c_int, [_vp, _fp]),
     "rt_camera_new": (C.c_int, [C.c_float, C.c_float, C.c_float, C.c_float, _f3, _f3, _f3,

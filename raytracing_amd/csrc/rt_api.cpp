@@ -51,6 +51,7 @@ struct Ctx {
     uint32_t *d_queue = nullptr;       // two counters used by alternate launches, see DevFrame::queue
     uint32_t launches = 0;             // render launches so far (picks the counter)
     uint32_t n_cus = 0;                // compute units of the device
+    uint32_t disc_plain = 0;           // see DevFrame::disc_plain
     bool have_frame = false;
 };
 
@@ -185,6 +186,9 @@ int rt_upload_tables(rt_ctx *ctx, const float *disc, const float *sphere, const 
     HIP_TRY(c, hipMemcpyAsync(c->d_sphere, sphere, 768 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_screen, screen, 16384 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // caller's memory may go away after return
+    c->disc_plain = 1;
+    for (int k = 0; k < 128; ++k)
+        if (!(std::fabs(disc[k]) >= 0x1p-90f && std::fabs(disc[k]) < 1.0f)) c->disc_plain = 0;
     c->have_tables = true;
     return RT_OK;
 }
@@ -216,13 +220,14 @@ int rt_upload_scene(rt_ctx *ctx, const rt_scene *s) {
     d.lds_run = hs.lds_run; d.lds_level = hs.lds_level;
     d.lds_first = hs.lds_first; d.lds_count = hs.lds_count;
     d.modes = hs.modes;
+    d.cheap_ok = hs.cheap_ok;
     if ((rc = upload(c, hs.runs, &d.runs)) != RT_OK || (rc = upload(c, hs.sph_geom, &d.sph_geom)) != RT_OK ||
         (rc = upload(c, hs.sph_mat, &d.sph_mat)) != RT_OK || (rc = upload(c, hs.sph_id, &d.sph_id)) != RT_OK ||
         (rc = upload(c, hs.planes, &d.planes)) != RT_OK || (rc = upload(c, hs.cubes, &d.cubes)) != RT_OK ||
         (rc = upload(c, hs.tris, &d.tris)) != RT_OK || (rc = upload(c, hs.tri_id, &d.tri_id)) != RT_OK ||
         (rc = upload(c, hs.cull_rec, &d.cull_rec)) != RT_OK ||
         (rc = upload(c, hs.tree_rec, &d.tree_rec)) != RT_OK || (rc = upload(c, hs.order, &d.order)) != RT_OK ||
-        (rc = upload(c, hs.mat_albedo, &d.mat_albedo)) != RT_OK || (rc = upload(c, hs.mat_kind, &d.mat_kind)) != RT_OK) {
+        (rc = upload(c, hs.mat_rec, &d.mat_rec)) != RT_OK) {
         std::string keep = c->err;
         free_scene(c);
         c->err = keep;
@@ -290,6 +295,7 @@ static int enqueue_render(Ctx *c, const rt_params *p, DevFrame fr, uint32_t stag
     const uint32_t n_bands = bands_of(p->height, p->band_begin, p->band_stride);
     if (n_bands == 0 || p->sample_count == 0) return RT_OK;
     rt_params part = *p;
+    fr.disc_plain = c->disc_plain;
     // development aid: RT_HIP_UNIT_PX=2|4|8|16|32|64 fixes the pixels of a tile per work unit
     // (default: by launch size, see rtk_launch_render); a unit's samples must fit a ring slot
     const char *up = std::getenv("RT_HIP_UNIT_PX");
@@ -324,7 +330,7 @@ int rt_render(rt_ctx *ctx, const rt_params *p) {
         return fail(c, RT_E_BADARG, "rt_render: width/height differ from rt_begin_frame");
     HIP_TRY(c, hipSetDevice(c->device));
     DevFrame fr{c->d_disc, c->d_sphere, c->d_screen, c->d_accum, c->d_ids, c->d_stage, c->d_segments,
-                nullptr, nullptr};
+                nullptr, nullptr, 0u};
     return enqueue_render(c, p, fr, c->stage_waves, c->d_queue, nullptr, 0);
 }
 
@@ -343,7 +349,7 @@ int rt_render_static(rt_ctx *ctx, const rt_params *p, void *accum_device, int32_
     HIP_TRY(c, hipSetDevice(c->device));
     DevFrame fr{c->d_disc, c->d_sphere, c->d_screen, static_cast<float4 *>(accum_device), ids_device,
                 c->fixed.stage, segments_device ? reinterpret_cast<unsigned long long *>(segments_device) : c->fixed.segments,
-                nullptr, nullptr};
+                nullptr, nullptr, 0u};
     return enqueue_render(c, p, fr, c->fixed.stage_waves, c->fixed.queue, c->fixed.queue, c->fixed.head_bytes);
 }
 
@@ -525,6 +531,31 @@ int rt_gather_packed(rt_ctx *const *ctxs, uint32_t n_ctx, uint32_t *out, size_t 
     // into the gather buffer directly)
     HIP_TRY(root, hipEventRecord(root->ev_block, root->stream));
     return read_back(root, out, root->d_packed, n_px * sizeof(uint32_t));
+}
+
+int rt_check_arith(rt_ctx *ctx, uint64_t operands, uint32_t seed, uint64_t mismatches[2]) {
+    Ctx *c = C(ctx);
+    if (!c) return RT_E_BADARG;
+    if (!mismatches || operands == 0 || operands > (1ull << 40)) return fail(c, RT_E_BADARG, "rt_check_arith: null result or count out of range");
+    HIP_TRY(c, hipSetDevice(c->device));
+    unsigned long long *bad = nullptr;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&bad), 2 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(bad, 0, 2 * sizeof(unsigned long long), c->stream);
+    const uint32_t rounds = 256u;
+    const uint64_t per_block = 256ull * rounds;
+    uint64_t blocks = (operands + per_block - 1) / per_block;
+    unsigned long long host[2] = {0, 0};
+    for (uint32_t part = 0; e == hipSuccess && blocks != 0; ++part) {
+        const uint32_t now = (uint32_t)std::min<uint64_t>(blocks, 1u << 20);
+        e = rtk_launch_check_arith(now, rounds, seed + 0x9E3779B9u * part, bad, c->stream);
+        blocks -= now;
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(host, bad, sizeof(host), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(bad);
+    if (e != hipSuccess) return hip_fail(c, e, "rt_check_arith");
+    mismatches[0] = host[0]; mismatches[1] = host[1];
+    return RT_OK;
 }
 
 int rt_timer_start(rt_ctx *ctx) {

@@ -63,12 +63,15 @@ struct DevScene {
     const float4 *tree_rec;   // RUN_TREE records, 12 float4 per step of eight boxes:
                               // per pair of boxes {lo0,lo1,hi0,hi1} for x, y, z
     const uint32_t *order;    // see DevRun::order_base
-    const float4 *mat_albedo; // r, g, b, param
-    const int32_t *mat_kind;
+    const float4 *mat_rec;    // 2 per material: {r, g, b, param}, {kind bits, 1/param, r0 front, r0 back}
+                              // (Dielectric: ratio and reflectance at normal incidence for either face,
+                              // src/geometry/mod.rs:313-317,327: functions of the material alone)
     // the top levels of ONE tree run are copied into LDS by every workgroup:
     // levels >= lds_level of run lds_run, tree_rec float4s [lds_first, +lds_count)
     uint32_t lds_run, lds_level, lds_first, lds_count;
     uint32_t modes;           // bit 0: some run is RUN_FLAT, bit 1: some run is RUN_TREE
+    uint32_t cheap_ok;        // every sphere has finite |centre| <= 2^30 and 2^-30 <= |radius| <= 2^30: rays of
+                              // moderate origin and length may take the short division and root sequences
 };
 #define DEV_SAMPLE_CHUNK 64u     // samples per pixel one launch renders at most
 // Staging ring: every wavefront of a render launch keeps the colours of its unfinished work
@@ -93,6 +96,8 @@ struct DevFrame {
     unsigned long long *segments;
     uint32_t *queue;          // work units of the running launch handed out so far (zero when it starts)
     uint32_t *queue_next;     // the counter the next launch on the stream will use: the running one zeroes it
+    uint32_t disc_plain;      // every entry of tbl_disc has 2^-90 <= |value| < 1: pixel column + entry is zero or
+                              // at least 2^-24, which lets the division by width - 1 take the short sequence
 };
 
 // stage_waves: wavefronts the staging ring behind fr.stage has room for (the grid is cut to it);
@@ -116,6 +121,9 @@ hipError_t rtk_launch_pack_bands(const float4 *accum, uint32_t *out, uint32_t W,
                                  uint32_t band_begin, uint32_t band_stride, uint32_t n_bands,
                                  hipStream_t stream);
 hipError_t rtk_launch_pack(const float4 *accum, uint32_t *out, uint32_t n_px, hipStream_t stream);
+// blocks x 256 threads x rounds operand triples through rtk::check_arith; bad[0..1] must be zeroed
+hipError_t rtk_launch_check_arith(uint32_t blocks, uint32_t rounds, uint32_t seed, unsigned long long *bad,
+                                  hipStream_t stream);
 hipError_t rtk_launch_compose_bands(const uint32_t *blocks, uint32_t *out, uint32_t W, uint32_t H, uint32_t n_ctx,
                                     size_t block_px, hipStream_t stream);
 

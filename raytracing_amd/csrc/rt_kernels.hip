@@ -72,6 +72,57 @@ __device__ __forceinline__ float trunc_i32_as_f32(float x) {
     return (float)(int32_t)x;
 }
 
+// ------------------------------------------------------------------ quotients and roots
+// `x / y` and sqrtf(x) have to be the correctly rounded binary32 results (Rust's `/` and
+// f32::sqrt).  The compiler's expansions of them take 11 and 16 instructions; a good part of
+// that scales operands near the ends of the exponent range and patches up zeros, infinities
+// and NaNs afterwards.  Away from those ends the steps in between, on their own, yield the
+// same bits, and quotients by one denominator can share the reciprocal:
+//     r = rcp(y);  r += r (1 - y r)                                  rcp_refined
+//     q = n r;     q += r (n - y q);   q += r (n - y q)              div_refined
+// for 2^-30 <= |y| <= 2^30 and 2^-90 <= |n| <= 2^60: no operand would have been scaled, the
+// quotient is normal, and the residuals n - y q (multiples of 2^-47 |n| at least) are exact;
+//     s = sqrt~(x), then one ulp down if x - s_down s <= 0, one up if x - s_up s > 0      sqrt_refined
+// for 2^-96 <= x (+inf and NaN come out as themselves).  Callers check the ranges, per wave,
+// and fall back to `/` and sqrtf; rtk::check_arith compares both on random operands.
+__device__ __forceinline__ float rcp_refined(float y) {
+    const float r = __builtin_amdgcn_rcpf(y);
+    return __builtin_fmaf(__builtin_fmaf(-y, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float div_refined(float n, float y, float r) {
+    float q = n * r;
+    q = __builtin_fmaf(__builtin_fmaf(-y, q, n), r, q);
+    return __builtin_fmaf(__builtin_fmaf(-y, q, n), r, q);
+}
+__device__ __forceinline__ float sqrt_refined(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float down = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float e_down = __builtin_fmaf(-down, s, x), e_up = __builtin_fmaf(-up, s, x);
+    float t = e_down <= 0.0f ? down : s;
+    t = e_up > 0.0f ? up : t;
+    return t;
+}
+#ifndef RTK_SHORT_ARITH
+#define RTK_SHORT_ARITH 1     // 0: `/` and sqrtf everywhere (for comparison)
+#endif
+constexpr float DIV_NUM_MIN = 0x1p-90f;    // smallest |numerator| of div_refined
+constexpr float SQRT_ARG_MIN = 0x1p-96f;   // smallest argument of sqrt_refined
+// three quotients by one denominator; `cheap` (wave-uniform) says that y is in div_refined's
+// range and no numerator above it; numerators below it (zero included) send the wave to `/`
+__device__ __forceinline__ V3 div3(V3 n, float y, bool cheap) {
+    const float small = __builtin_fminf(__builtin_fminf(__builtin_fabsf(n.x), __builtin_fabsf(n.y)), __builtin_fabsf(n.z));
+    if (cheap && __builtin_amdgcn_ballot_w64(!(small >= DIV_NUM_MIN)) == 0ull) {
+        const float r = rcp_refined(y);
+        return mk(div_refined(n.x, y, r), div_refined(n.y, y, r), div_refined(n.z, y, r));
+    }
+    return n / y;
+}
+// sqrtf for arguments that are rarely below sqrt_refined's range
+__device__ __forceinline__ float sqrt_mostly(float x) {
+    if (RTK_SHORT_ARITH && __builtin_amdgcn_ballot_w64(!(x >= SQRT_ARG_MIN)) == 0ull) return sqrt_refined(x);
+    return __builtin_sqrtf(x);
+}
+
 // integer mixer of the sampling schedule (two multiply-xorshift rounds)
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du;
@@ -96,11 +147,10 @@ __device__ __forceinline__ const RT_CONST_AS T *const_ptr(const S *p) {
 }
 struct SceneView {
     const RT_CONST_AS u16v *runs;         // two per DevRun
-    const RT_CONST_AS f4 *sph_geom, *planes, *cubes, *tris, *mat_albedo;
+    const RT_CONST_AS f4 *sph_geom, *planes, *cubes, *tris, *mat_rec;
     const RT_CONST_AS f16 *cull_rec;      // RUN_FLAT: two per step of eight records
     const RT_CONST_AS f4 *tree_rec;       // RUN_TREE: twelve per step of eight boxes
     const RT_CONST_AS uint32_t *sph_mat, *sph_id, *tri_id, *order;
-    const RT_CONST_AS int32_t *mat_kind;
     uint32_t n_runs, need_ff_shared;
     uint32_t lds_run, lds_level, lds_first;
     unsigned long long *stats;   // fr.segments; slots 1..7 are instrumentation (RTK_STATS builds)
@@ -113,14 +163,13 @@ __device__ __forceinline__ SceneView view_of(const DevScene &sc, unsigned long l
     v.planes = const_ptr<f4>(sc.planes);
     v.cubes = const_ptr<f4>(sc.cubes);
     v.tris = const_ptr<f4>(sc.tris);
-    v.mat_albedo = const_ptr<f4>(sc.mat_albedo);
+    v.mat_rec = const_ptr<f4>(sc.mat_rec);
     v.cull_rec = const_ptr<f16>(sc.cull_rec);
     v.tree_rec = const_ptr<f4>(sc.tree_rec);
     v.sph_mat = const_ptr<uint32_t>(sc.sph_mat);
     v.sph_id = const_ptr<uint32_t>(sc.sph_id);
     v.tri_id = const_ptr<uint32_t>(sc.tri_id);
     v.order = const_ptr<uint32_t>(sc.order);
-    v.mat_kind = const_ptr<int32_t>(sc.mat_kind);
     v.n_runs = sc.n_runs;
     v.need_ff_shared = sc.need_ff_shared;
     v.lds_run = sc.lds_run; v.lds_level = sc.lds_level; v.lds_first = sc.lds_first;
@@ -250,28 +299,46 @@ struct Hit {
 __device__ __forceinline__ int32_t list_position(const RT_CONST_AS uint32_t *by_slot, uint32_t slot, int32_t id) {
     return id == ID_LATER ? (int32_t)by_slot[slot] : id;
 }
-// Sphere::hit, src/geometry/mod.rs:60-94; `a` is |dir|^2 (:63)
+// What the exact tests need to know about the ray beyond origin and direction: `a` is |dir|^2
+// (Sphere::hit, src/geometry/mod.rs:63, the same for every sphere).  `cheap` is wave-uniform and
+// says that every ray being traced has 2^-24 <= a <= 2^24 and |origin coordinates| <= 2^30, every
+// sphere of the scene moderate coordinates (DevScene::cheap_ok) and t_min >= 2^-20: then the
+// quotients by `a` may be div_refined with the shared reciprocal inv_a.  (Their numerators stay
+// below 2^60; one below 2^-90 gives a root below 2^-66, which both this and `/` put in front of
+// t_min, so its bits are never looked at.)
+struct RayAux { float a, inv_a; bool cheap; };
+// Sphere::hit, src/geometry/mod.rs:60-94
 // (nan_out, where given, is set when the accepted distance is NaN)
 __device__ __forceinline__ void sphere_exact(const SceneView &sc, uint32_t slot, int32_t id, const Ray &ray,
-                                             float a, float t_min, Hit &h, bool &ff_shared, bool *nan_out = nullptr) {
+                                             const RayAux &aux, float t_min, Hit &h, bool &ff_shared, bool *nan_out = nullptr) {
+    const float a = aux.a;
     const f4 g = sc.sph_geom[slot];   // cx, cy, cz, radius
     V3 oc = ray.o - mk(g.x, g.y, g.z);
     float half_b = dot(oc, ray.d);
     float c = len2(oc) - g.w * g.w;
     float disc = half_b * half_b - a * c;
     if (disc < 0.0f) return;
-    float d_sqrt = __builtin_sqrtf(disc);
-    float root = -(half_b + d_sqrt) / a;
-    if (root < t_min || h.t < root) {
-        root = (-half_b + d_sqrt) / a;
-        if (root < t_min || h.t < root) return;
+    float root;
+    float d_sqrt = sqrt_mostly(disc);
+    if (aux.cheap) {
+        root = div_refined(-(half_b + d_sqrt), a, aux.inv_a);
+        if (root < t_min || h.t < root) {
+            root = div_refined(-half_b + d_sqrt, a, aux.inv_a);
+            if (root < t_min || h.t < root) return;
+        }
+    } else {
+        root = -(half_b + d_sqrt) / a;
+        if (root < t_min || h.t < root) {
+            root = (-half_b + d_sqrt) / a;
+            if (root < t_min || h.t < root) return;
+        }
     }
     if (root == h.t && list_position(sc.sph_id, slot, id) < list_position(sc.sph_id, h.slot, h.id)) return;
     h.t = root; h.kind = DEV_SPHERE; h.slot = slot; h.id = id;
     if (nan_out) *nan_out = root != root;
     if (sc.need_ff_shared) {
         V3 p = ray.o + ray.d * root;
-        V3 outward = (p - mk(g.x, g.y, g.z)) / g.w;
+        V3 outward = div3(p - mk(g.x, g.y, g.z), g.w, aux.cheap);
         ff_shared = dot(ray.d, outward) < 0.0f;
     }
 }
@@ -402,7 +469,7 @@ __device__ __forceinline__ uint32_t cull_step(const Cull &cull, float oo_keep, c
 template <int KIND>
 __device__ __forceinline__ void leaf_exact(const SceneView &sc, const RunView &run, uint32_t first_in_run,
                                            uint32_t any_bits, uint32_t lane_bits, bool list_order,
-                                           const Ray &ray, float a, float t_min, Hit &h, bool &ff_shared) {
+                                           const Ray &ray, const RayAux &aux, float t_min, Hit &h, bool &ff_shared) {
     if (first_in_run >= run.count) return;          // a step of padding only
     const uint32_t left = run.count - first_in_run;
 #pragma unroll 1
@@ -413,7 +480,7 @@ __device__ __forceinline__ void leaf_exact(const SceneView &sc, const RunView &r
         const int32_t id = list_order ? (int32_t)(run.id0 + first_in_run + k)
                                       : (int32_t)(KIND == DEV_SPHERE ? sc.sph_id[slot] : sc.tri_id[slot]);
         if ((lane_bits >> k) & 1u) {
-            if (KIND == DEV_SPHERE) sphere_exact(sc, slot, id, ray, a, t_min, h, ff_shared);
+            if (KIND == DEV_SPHERE) sphere_exact(sc, slot, id, ray, aux, t_min, h, ff_shared);
             else tri_exact(sc, slot, id, ray, t_min, h, ff_shared);
         }
     }
@@ -429,7 +496,7 @@ __device__ __forceinline__ void leaf_exact(const SceneView &sc, const RunView &r
 // a whole step to arrive.
 // ----------------------------------------------------------------------
 __device__ __forceinline__ void scan_flat(const SceneView &sc, const RunView &run, const Cull &cull, bool tracing,
-                                          const Ray &ray, float a, float t_min, Hit &h, bool &ff_shared) {
+                                          const Ray &ray, const RayAux &aux, float t_min, Hit &h, bool &ff_shared) {
     const float oo_keep = tracing ? cull.oo * run.level_keep(0) : __builtin_inff();
     const RT_CONST_AS f16 *rec = sc.cull_rec + 2u * run.level_base(0);
     const uint32_t trips = run.top_steps / 2u;
@@ -444,7 +511,7 @@ __device__ __forceinline__ void scan_flat(const SceneView &sc, const RunView &ru
         lane_bits = cull_step(cull, oo_keep, a0, a1, any_bits);
         if (any_bits) {
             RTK_COUNT(sc, 3, 1);
-            leaf_exact<DEV_SPHERE>(sc, run, 16u * b, any_bits, lane_bits, true, ray, a, t_min, h, ff_shared);
+            leaf_exact<DEV_SPHERE>(sc, run, 16u * b, any_bits, lane_bits, true, ray, aux, t_min, h, ff_shared);
         }
         asm volatile("; records of the odd step have arrived" ::"s"(b0.s0), "s"(b1.s0));
         __builtin_amdgcn_sched_barrier(0);
@@ -454,7 +521,7 @@ __device__ __forceinline__ void scan_flat(const SceneView &sc, const RunView &ru
         lane_bits = cull_step(cull, oo_keep, b0, b1, any_bits);
         if (any_bits) {
             RTK_COUNT(sc, 3, 1);
-            leaf_exact<DEV_SPHERE>(sc, run, 16u * b + 8u, any_bits, lane_bits, true, ray, a, t_min, h, ff_shared);
+            leaf_exact<DEV_SPHERE>(sc, run, 16u * b + 8u, any_bits, lane_bits, true, ray, aux, t_min, h, ff_shared);
         }
     }
 }
@@ -490,7 +557,7 @@ __device__ __forceinline__ void scan_flat(const SceneView &sc, const RunView &ru
 template <int KIND>
 __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &run, bool walking,
                                           TreeTable &tbl, const f4 *tree_top, uint32_t lds_from_level,
-                                          const Ray &ray, float a, float t_min, Hit &h, bool &ff_shared) {
+                                          const Ray &ray, const RayAux &aux, float t_min, Hit &h, bool &ff_shared) {
     // per-level constants where a lane can index them by its own level
 #pragma unroll
     for (uint32_t L = 0; L < DEV_MAX_LEVELS; ++L) { tbl.base[L] = run.lo[8 + L]; tbl.count[L] = run.hi[L]; }
@@ -595,7 +662,7 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
                         const uint32_t slot = run.first + 8u * st + k;
                         RTK_COUNT(sc, 4, 1);
                         RTK_COUNT_ANY(sc, 7, 1);
-                        if (KIND == DEV_SPHERE) sphere_exact(sc, slot, ID_LATER, ray, a, t_min, h, ff_shared, &got_nan);
+                        if (KIND == DEV_SPHERE) sphere_exact(sc, slot, ID_LATER, ray, aux, t_min, h, ff_shared, &got_nan);
                         else tri_exact(sc, slot, ID_LATER, ray, t_min, h, ff_shared, &got_nan);
                     }
                     // next pending sibling, of this node or of its nearest ancestor that has one
@@ -629,8 +696,9 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
 template <int KIND>
 __device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &run, bool tracing,
                                           TreeTable &tbl, const f4 *tree_top, uint32_t lds_from_level,
-                                          const Ray &ray, float a, float t_min, Hit &h, bool &ff_shared) {
+                                          const Ray &ray, const RayAux &aux, float t_min, Hit &h, bool &ff_shared) {
     const float big = 1e18f;
+    const float a = aux.a;
     const uint32_t lane = threadIdx.x & 63u;
     const bool tame = a > 1e-12f && a < 1e12f && h.t == h.t &&
                       __builtin_fabsf(ray.o.x) < big && __builtin_fabsf(ray.o.y) < big && __builtin_fabsf(ray.o.z) < big;
@@ -648,11 +716,11 @@ __device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &ru
         for (uint32_t k = 0; k < n_unbounded; ++k) {
             const uint32_t slot = run.first + sc.order[run.order_base + run.count + k];
             if (walking && h.t == h.t) {
-                if (KIND == DEV_SPHERE) sphere_exact(sc, slot, ID_LATER, ray, a, t_min, h, ff_shared);
+                if (KIND == DEV_SPHERE) sphere_exact(sc, slot, ID_LATER, ray, aux, t_min, h, ff_shared);
                 else tri_exact(sc, slot, ID_LATER, ray, t_min, h, ff_shared);
             }
         }
-        walk_tree<KIND>(sc, run, walking && h.t == h.t, tbl, tree_top, lds_from_level, ray, a, t_min, h, ff_shared);
+        walk_tree<KIND>(sc, run, walking && h.t == h.t, tbl, tree_top, lds_from_level, ray, aux, t_min, h, ff_shared);
         if (walking && h.id == ID_LATER) h.id = (int32_t)(KIND == DEV_SPHERE ? sc.sph_id[h.slot] : sc.tri_id[h.slot]);
         if (walking && h.t != h.t) {
             const uint32_t bits = tbl.entry_bits[lane];
@@ -665,7 +733,7 @@ __device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &ru
         for (uint32_t k = 0; k < run.count; ++k) {
             const uint32_t slot = run.first + sc.order[run.order_base + k];
             if (listed) {
-                if (KIND == DEV_SPHERE) sphere_exact(sc, slot, (int32_t)(run.id0 + k), ray, a, t_min, h, ff_shared);
+                if (KIND == DEV_SPHERE) sphere_exact(sc, slot, (int32_t)(run.id0 + k), ray, aux, t_min, h, ff_shared);
                 else tri_exact(sc, slot, (int32_t)(run.id0 + k), ray, t_min, h, ff_shared);
             }
         }
@@ -679,7 +747,7 @@ __device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &ru
 // of the final hit is rebuilt afterwards from the same inputs.
 // ----------------------------------------------------------------------
 template <int MODES>
-__device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, float t_min, bool tracing,
+__device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, const RayAux &aux, float t_min, bool tracing,
                                           TreeTable &tbl, const f4 *tree_top, Hit &h) {
     h.t = __builtin_inff();
     h.kind = -1;
@@ -687,7 +755,7 @@ __device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, f
     h.id = -1;
     h.ff = true;
     bool ff_shared = true;   // temp_hr.front_face, default true (src/geometry/mod.rs:36-39,241)
-    const float a = len2(ray.d);   // Sphere::hit :63, the same for every sphere
+    const float a = aux.a;
     Cull cull;
     bool have_cull = false;
     RTK_COUNT(sc, 1, 1);
@@ -699,15 +767,15 @@ __device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, f
             if ((MODES & 1) && run.mode == RUN_FLAT) {
                 // the ball rejection test needs the unit direction and |o|^2
                 if (!have_cull) { cull = cull_setup(ray, a); have_cull = true; }
-                scan_flat(sc, run, cull, tracing, ray, a, t_min, h, ff_shared);
+                scan_flat(sc, run, cull, tracing, ray, aux, t_min, h, ff_shared);
             } else if ((MODES & 2) && run.kind == DEV_SPHERE) {
-                scan_tree<DEV_SPHERE>(sc, run, tracing, tbl, tree_top, from, ray, a, t_min, h, ff_shared);
+                scan_tree<DEV_SPHERE>(sc, run, tracing, tbl, tree_top, from, ray, aux, t_min, h, ff_shared);
             } else if (MODES & 2) {
-                scan_tree<DEV_TRI>(sc, run, tracing, tbl, tree_top, from, ray, a, t_min, h, ff_shared);
+                scan_tree<DEV_TRI>(sc, run, tracing, tbl, tree_top, from, ray, aux, t_min, h, ff_shared);
             }
         } else if (run.kind == DEV_SPHERE) {
             for (uint32_t k = 0; k < run.count; ++k)
-                sphere_exact(sc, run.first + k, (int32_t)(run.id0 + k), ray, a, t_min, h, ff_shared);
+                sphere_exact(sc, run.first + k, (int32_t)(run.id0 + k), ray, aux, t_min, h, ff_shared);
         } else if (run.kind == DEV_PLANE) {
             // Plane::hit, src/geometry/mod.rs:112-130
             for (uint32_t k = 0; k < run.count; ++k) {
@@ -753,7 +821,7 @@ __device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, f
 // the primitive's hit() filled it, then run its material's scatter.
 // Returns the material index; ray is replaced by the scattered ray.
 __device__ __forceinline__ uint32_t shade_hit(const SceneView &sc, const float *tbl_sphere, Ray &ray, V3 ud, const Hit &h,
-                                              float sp_bn, uint32_t &path_counter, uint32_t path_key,
+                                              bool cheap, float sp_bn, uint32_t &path_counter, uint32_t path_key,
                                               uint32_t bounce) {
     V3 p = ray.o + ray.d * h.t;   // Ray::at, src/ray/mod.rs:19-21
     V3 normal;
@@ -762,7 +830,7 @@ __device__ __forceinline__ uint32_t shade_hit(const SceneView &sc, const float *
     if (h.kind == DEV_SPHERE) {
         // src/geometry/mod.rs:81-86
         const f4 g = sc.sph_geom[h.slot];
-        V3 outward = (p - mk(g.x, g.y, g.z)) / g.w;
+        V3 outward = div3(p - mk(g.x, g.y, g.z), g.w, cheap);   // |p - c| < 2^60 by the bounds `cheap` stands for
         ff = dot(ray.d, outward) < 0.0f;
         normal = ff ? outward : -outward;
         mat = sc.sph_mat[h.slot];
@@ -794,8 +862,9 @@ __device__ __forceinline__ uint32_t shade_hit(const SceneView &sc, const float *
         normal = ff ? outward : -outward;
         mat = __float_as_uint(v0.w);
     }
-    const f4 ma = sc.mat_albedo[mat];   // r, g, b, param
-    const int mk_ = sc.mat_kind[mat];
+    const f4 ma = sc.mat_rec[2u * mat];        // r, g, b, param
+    const f4 mb = sc.mat_rec[2u * mat + 1u];   // kind, 1/param, r0 for a front face, r0 for a back face
+    const int mk_ = (int)__float_as_uint(mb.x);
     V3 dir;
     // `ud` is unit_vector(r_in.direction) (src/geometry/mod.rs:276,326), the same value for
     // whichever material needs it; the unit-sphere draw of Metal and Lambertian is one lookup
@@ -814,14 +883,14 @@ __device__ __forceinline__ uint32_t shade_hit(const SceneView &sc, const float *
         if (dir.x < 0.0f && dir.y < 0.0f && dir.z < 0.0f) dir = normal;   // is_near_zero, src/vector/mod.rs:29-32
     } else {
         // Dielectric::scatter, src/geometry/mod.rs:323-346
-        float ratio = ff ? 1.0f / ma.w : ma.w;
+        float ratio = ff ? mb.y : ma.w;   // 1.0 / ir or ir
         float cos_theta = rmin(dot(-ud, normal), 1.0f);
-        float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+        float sin_theta = sqrt_mostly(1.0f - cos_theta * cos_theta);
         bool refl = ratio * sin_theta > 1.0f;
         if (!refl) {
-            // reflectance, src/geometry/mod.rs:313-317; coin: hash of (path, bounce)
-            float r0 = (1.0f - ratio) / (1.0f + ratio);
-            r0 = r0 * r0;
+            // reflectance, src/geometry/mod.rs:313-317 (r0 = ((1-ratio)/(1+ratio))^2 comes with the
+            // material); coin: hash of (path, bounce)
+            float r0 = ff ? mb.z : mb.w;
             float refl_p = r0 + (1.0f - r0) * powi5(1.0f - cos_theta);
             uint32_t rb = mix32(path_key + GOLDEN32 * (bounce + 1u));
             float coin = (float)(rb >> 8) * (1.0f / 16777216.0f);
@@ -833,7 +902,7 @@ __device__ __forceinline__ uint32_t shade_hit(const SceneView &sc, const float *
             // refract, src/geometry/mod.rs:307-312
             float ct = rmin(dot(-ud, normal), 1.0f);
             V3 perp = (ud + normal * ct) * ratio;
-            V3 par = (-normal) * __builtin_sqrtf(__builtin_fabsf(1.0f - len2(perp)));
+            V3 par = (-normal) * sqrt_mostly(__builtin_fabsf(1.0f - len2(perp)));
             dir = perp + par;
         }
     }
@@ -843,10 +912,18 @@ __device__ __forceinline__ uint32_t shade_hit(const SceneView &sc, const float *
 }
 
 // sky branch of ray_colour, src/raytracer.rs:81-91
+// (for a unit direction the three channels lie in 0.25 .. 1, far inside sqrt_refined's range)
 __device__ __forceinline__ V3 sky(V3 ud, bool gamma) {
     float t = 0.5f * ud.y + 1.0f;
     V3 c = mk(1.0f, 1.0f, 1.0f) * (1.0f - t) + mk(0.5f, 0.7f, 1.0f) * t;
-    if (gamma) { c.x = __builtin_sqrtf(c.x); c.y = __builtin_sqrtf(c.y); c.z = __builtin_sqrtf(c.z); }
+    if (gamma) {
+        const float low = __builtin_fminf(__builtin_fminf(c.x, c.y), c.z);
+        if (RTK_SHORT_ARITH && __builtin_amdgcn_ballot_w64(!(low >= SQRT_ARG_MIN)) == 0ull) {
+            c.x = sqrt_refined(c.x); c.y = sqrt_refined(c.y); c.z = sqrt_refined(c.z);
+        } else {
+            c.x = __builtin_sqrtf(c.x); c.y = __builtin_sqrtf(c.y); c.z = __builtin_sqrtf(c.z);
+        }
+    }
     return c;
 }
 
@@ -899,6 +976,13 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
 
     const uint32_t W = p.width, H = p.height;
     const bool gamma = p.gamma != 0;
+    // see RayAux
+    const bool cheap_frame = RTK_SHORT_ARITH && dsc.cheap_ok != 0u && p.t_min >= 0x1p-20f;
+    // (column + disc entry) / (W - 1), src/raytracer.rs:255-256: the denominators are 1 .. 65535 and the
+    // numerators, for a table without tiny entries, zero-free and in 2^-90 .. 2^17
+    const bool cheap_uv = RTK_SHORT_ARITH && fr.disc_plain != 0u && W >= 2u && H >= 2u;
+    const float w1 = (float)(W - 1u), h1 = (float)(H - 1u);
+    const float inv_w1 = rcp_refined(w1), inv_h1 = rcp_refined(h1);
     UnitRing &ring = lds.ring[wave];
     // this wave's part of the staging ring: DEV_STAGE_SLOTS units of up to 2^ITEM_BITS colours;
     // an item's place is its own number, ring slot << ITEM_BITS | index in the unit
@@ -949,8 +1033,9 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
         uint32_t k1 = (2u * n + 1u) & 63u, k2 = (2u * n + 2u) & 63u;
         float ox = lds.disc[2 * k1], oy = lds.disc[2 * k1 + 1];
         float la = lds.disc[2 * k2], lb = lds.disc[2 * k2 + 1];
-        float u = ((float)w.i + ox) / (float)(W - 1u);
-        float v = ((float)w.j + oy) / (float)(H - 1u);
+        float u, v;
+        if (cheap_uv) { u = div_refined((float)w.i + ox, w1, inv_w1); v = div_refined((float)w.j + oy, h1, inv_h1); }
+        else { u = ((float)w.i + ox) / w1; v = ((float)w.j + oy) / h1; }
         ray = get_ray(cam, u, v, la, lb);
         path_counter = path_key_at(w);
         depth_left = p.max_bounces;
@@ -1035,7 +1120,16 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
 #ifdef RTK_TIMES
         const unsigned long long tm0 = __builtin_readcyclecounter();
 #endif
-        scan_list<MODES>(sc, ray, p.t_min, alive, lds.tree[wave], lds.tree_top, h);
+        // |direction|^2 and whether the short division and root sequences apply (see RayAux)
+        RayAux aux;
+        aux.a = len2(ray.d);
+        {
+            const float far = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ray.o.x), __builtin_fabsf(ray.o.y)), __builtin_fabsf(ray.o.z));
+            const bool moderate = aux.a >= 0x1p-24f && aux.a <= 0x1p24f && far <= 0x1p30f;
+            aux.cheap = cheap_frame && __builtin_amdgcn_ballot_w64(alive && !moderate) == 0ull;
+            aux.inv_a = rcp_refined(aux.a);
+        }
+        scan_list<MODES>(sc, ray, aux, p.t_min, alive, lds.tree[wave], lds.tree_top, h);
 #ifdef RTK_TIMES
         const unsigned long long tm1 = __builtin_readcyclecounter();
         tm_scan += tm1 - tm0;
@@ -1051,11 +1145,12 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
             if (at.s == 0u && n_stack == 0u) fr.primary_ids[pix_out] = h.id;
             // unit_vector(direction): the sky (src/raytracer.rs:82), Metal and Dielectric all start
             // from it; computed once for the wave instead of once per branch
-            const V3 ud = unit(ray.d);
+            // (cheap: 2^-12 <= |d| <= 2^12, every component at most that)
+            const V3 ud = div3(ray.d, aux.cheap ? sqrt_refined(aux.a) : __builtin_sqrtf(aux.a), aux.cheap);
             V3 c;
             uint32_t n_hits = n_stack;
             if (h.kind >= 0) {
-                uint32_t mat = shade_hit(sc, lds.sphere, ray, ud, h, sp_bn, path_counter, path_key_at(at), n_stack);
+                uint32_t mat = shade_hit(sc, lds.sphere, ray, ud, h, aux.cheap, sp_bn, path_counter, path_key_at(at), n_stack);
                 lds.mat_stack[wave][n_stack][lane] = mat;
                 n_hits = n_stack + 1u;
                 depth_left -= 1;
@@ -1077,7 +1172,7 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
                     const uint32_t m1 = lds.mat_stack[wave][k >= 2u ? k - 2u : 0u][lane];
                     const uint32_t m2 = lds.mat_stack[wave][k >= 3u ? k - 3u : 0u][lane];
                     const uint32_t m3 = lds.mat_stack[wave][k >= 4u ? k - 4u : 0u][lane];
-                    const f4 a0 = sc.mat_albedo[m0], a1 = sc.mat_albedo[m1], a2 = sc.mat_albedo[m2], a3 = sc.mat_albedo[m3];
+                    const f4 a0 = sc.mat_rec[2u * m0], a1 = sc.mat_rec[2u * m1], a2 = sc.mat_rec[2u * m2], a3 = sc.mat_rec[2u * m3];
                     c = mk(a0.x, a0.y, a0.z) * c;
                     if (k >= 2u) c = mk(a1.x, a1.y, a1.z) * c;
                     if (k >= 3u) c = mk(a2.x, a2.y, a2.z) * c;
@@ -1187,6 +1282,34 @@ void compose_bands(const uint32_t *__restrict__ blocks, uint32_t *__restrict__ o
     out[(size_t)(H - 1u - j) * W + x] = blocks[(size_t)g * block_px + (size_t)m * W + x];
 }
 
+// div_refined and sqrt_refined against `/` and sqrtf on random operands of their stated ranges
+// (exponents uniform over the range, one mantissa in four all zeros, all ones or one bit off
+// either): bad[0] counts quotients that differ in any bit, bad[1] roots.
+__global__ __launch_bounds__(256)
+void check_arith(uint32_t rounds, uint32_t seed, unsigned long long *bad) {
+    uint32_t state = mix32((blockIdx.x * blockDim.x + threadIdx.x) ^ mix32(seed));
+    auto next = [&]() { state = state * 747796405u + 2891336453u; return mix32(state); };
+    auto operand = [&](int e_min, int e_max, bool negative_too) {
+        const uint32_t w = next(), pick = next();
+        uint32_t mant = w & 0x7fffffu;
+        if ((pick & 3u) == 0u) {
+            const uint32_t edge[4] = {0u, 0x7fffffu, 1u, 0x7ffffeu};
+            mant = edge[(pick >> 2) & 3u];
+        }
+        const uint32_t e = (uint32_t)(127 + e_min) + (pick >> 8) % (uint32_t)(e_max - e_min + 1);
+        return __uint_as_float((negative_too ? (w & 0x80000000u) : 0u) | (e << 23) | mant);
+    };
+    uint32_t bad_div = 0, bad_sqrt = 0;
+    for (uint32_t k = 0; k < rounds; ++k) {
+        const float y = operand(-30, 29, true), n = operand(-90, 59, true), x = operand(-96, 127, false);
+        const float q = div_refined(n, y, rcp_refined(y));
+        bad_div += __float_as_uint(q) != __float_as_uint(n / y);
+        bad_sqrt += __float_as_uint(sqrt_refined(x)) != __float_as_uint(__builtin_sqrtf(x));
+    }
+    if (bad_div) atomicAdd(bad, (unsigned long long)bad_div);
+    if (bad_sqrt) atomicAdd(bad + 1, (unsigned long long)bad_sqrt);
+}
+
 }  // namespace rtk
 
 // ------------------------------------------------------------ static scratch
@@ -1279,6 +1402,11 @@ hipError_t rtk_launch_compose_bands(const uint32_t *blocks, uint32_t *out, uint3
                                     size_t block_px, hipStream_t stream) {
     dim3 grid((W + 255u) / 256u, H, 1), block(256, 1, 1);
     hipLaunchKernelGGL(rtk::compose_bands, grid, block, 0, stream, blocks, out, W, H, n_ctx, block_px);
+    return hipGetLastError();
+}
+hipError_t rtk_launch_check_arith(uint32_t blocks, uint32_t rounds, uint32_t seed, unsigned long long *bad,
+                                  hipStream_t stream) {
+    hipLaunchKernelGGL(rtk::check_arith, dim3(blocks, 1, 1), dim3(256, 1, 1), 0, stream, rounds, seed, bad);
     return hipGetLastError();
 }
 hipError_t rtk_launch_pack(const float4 *accum, uint32_t *out, uint32_t n_px, hipStream_t stream) {

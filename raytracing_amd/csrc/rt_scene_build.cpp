@@ -273,8 +273,21 @@ int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::strin
     if (!ok) { err = "ids are not a permutation of the list, or a material index is out of range"; return RT_E_BADARG; }
 
     for (uint32_t m = 0; m < s->n_materials; ++m) {
-        sc.mat_albedo.push_back(make_float4(s->mat_r[m], s->mat_g[m], s->mat_b[m], s->mat_param[m]));
-        sc.mat_kind.push_back(s->mat_kind[m]);
+        sc.mat_rec.push_back(make_float4(s->mat_r[m], s->mat_g[m], s->mat_b[m], s->mat_param[m]));
+        // Dielectric::scatter, src/geometry/mod.rs:327: refraction_ratio = 1.0/ir for a front face, ir
+        // otherwise; reflectance :313-317: r0 = ((1-ratio)/(1+ratio))^2.  Functions of the material alone,
+        // evaluated here once in the same f32 operations.
+        const float ir = s->mat_param[m], inv_ir = 1.0f / ir;
+        float r0_front = (1.0f - inv_ir) / (1.0f + inv_ir), r0_back = (1.0f - ir) / (1.0f + ir);
+        r0_front = r0_front * r0_front;
+        r0_back = r0_back * r0_back;
+        sc.mat_rec.push_back(make_float4(bits_to_float((uint32_t)s->mat_kind[m]), inv_ir, r0_front, r0_back));
+    }
+    for (uint32_t k = 0; k < s->n_spheres; ++k) {
+        const float lim = 1073741824.0f, r = std::abs(s->sph_r[k]);
+        if (!(std::abs(s->sph_cx[k]) <= lim && std::abs(s->sph_cy[k]) <= lim && std::abs(s->sph_cz[k]) <= lim &&
+              r <= lim && r >= 1.0f / lim))
+            sc.cheap_ok = 0;
     }
 
     const double LEAF_EPS_SPHERE = 1.0 / 65536.0;   // proven bound of the kernel's test, see cull_pair

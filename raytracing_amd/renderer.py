@@ -129,6 +129,12 @@ class Renderer:
     def sync(self):
         self._check(self._lib.rt_sync(self._ctx))
 
+    def check_arith(self, operands, seed=0):
+        """rt_check_arith: (quotients, roots) of the short sequences that differ from `/` and sqrt."""
+        bad = (C.c_uint64 * 2)()
+        self._check(self._lib.rt_check_arith(self._ctx, operands, seed, bad))
+        return int(bad[0]), int(bad[1])
+
     def timer_start(self):
         self._check(self._lib.rt_timer_start(self._ctx))
 
