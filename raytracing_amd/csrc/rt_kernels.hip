@@ -155,7 +155,7 @@ struct SceneView {
     uint32_t lds_run, lds_level, lds_first;
     unsigned long long *stats;   // fr.segments; slots 1..7 are instrumentation (RTK_STATS builds)
 };
-__device__ __forceinline__ SceneView view_of(const DevScene &sc, unsigned long long *stats) {
+__device__ __forceinline__ SceneView view_of(const RT_CONST_AS DevScene &sc, unsigned long long *stats) {
     SceneView v;
     v.stats = stats;
     v.runs = const_ptr<u16v>(sc.runs);
@@ -193,6 +193,14 @@ __device__ __forceinline__ RunView load_run(const SceneView &sc, uint32_t r) {
 
 // wavefronts per workgroup: 8 when a tree copy in LDS is shared, else 4
 __host__ __device__ constexpr int waves_of(int modes) { return (modes & 2) ? RTK_TREE_WAVES : 4; }
+// wavefronts per SIMD the kernel is compiled for
+#ifndef RTK_OCC
+#define RTK_OCC 4
+#endif
+#ifndef RTK_OCC0
+#define RTK_OCC0 5           // scenes without long runs: 92 VGPRs, no spills (six waves spill 20; measured on the
+#endif                       // default scene at 1080p, 64 samples: 6.61 ms with four waves per SIMD, 5.92 with five, 6.98 with six)
+__host__ __device__ constexpr int occ_of(int modes) { return modes == 0 ? RTK_OCC0 : RTK_OCC; }
 constexpr int TILE = 8;   // 8x8 pixels per wavefront
 
 struct TreeTable {
@@ -220,13 +228,14 @@ struct Lds {
     uint32_t mat_stack[waves_of(MODES)][RT_MAX_BOUNCES][64];
     TreeTable tree[waves_of(MODES)];                    // per-level constants of the run being walked
     UnitRing ring[waves_of(MODES)];                     // the units each wave has in flight
+    float uv[4];                                        // width - 1, height - 1, their refined reciprocals
     f4 tree_top[(MODES & 2) ? DEV_TREE_LDS_F4 : 1];     // top levels of one tree (DevScene::lds_*)
 };
 
 struct Ray { V3 o, d; };
 
 // Camera::get_ray, src/camera/mod.rs:75-79
-__device__ __forceinline__ Ray get_ray(const rt_camera &c, float s, float t, float da, float db) {
+__device__ __forceinline__ Ray get_ray(const RT_CONST_AS rt_camera &c, float s, float t, float da, float db) {
     V3 origin = mk(c.origin[0], c.origin[1], c.origin[2]);
     V3 llc = mk(c.lower_left_corner[0], c.lower_left_corner[1], c.lower_left_corner[2]);
     V3 hor = mk(c.horizontal[0], c.horizontal[1], c.horizontal[2]);
@@ -947,53 +956,63 @@ __device__ __forceinline__ V3 sky(V3 ud, bool gamma) {
 // ----------------------------------------------------------------------
 constexpr uint32_t ITEM_BITS = DEV_STAGE_ITEM_BITS;   // item index inside a unit: pixels of the unit x samples of the launch <= 512
 
+// the arguments of render_tiles as they lie in the kernel's argument block
+struct KernArgs { DevScene dsc; rt_camera cam; rt_params p; DevFrame fr; uint32_t n_bands, unit_px_log2; };
+
 template <int MODES>
-#ifndef RTK_OCC
-#define RTK_OCC 4
-#endif
 // Two 8-wave workgroups per CU: four waves per SIMD, at most 128 VGPRs each (some per-item
 // state is spilled around the walk).  Measured alternatives on the 10,000-sphere frame: three
 // waves per SIMD without spills (one 12-wave workgroup per CU) -14 %, 4-wave workgroups with
 // a 16 KB tree copy -5 %, 16-wave workgroups the same, 96 VGPRs for five waves per SIMD -40 %;
 // 6- or 10-wave workgroups fit only once per CU.
-__global__ __launch_bounds__(waves_of(MODES) * 64, RTK_OCC)
-void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_t n_bands, uint32_t unit_px_log2) {
+__global__ __launch_bounds__(waves_of(MODES) * 64, occ_of(MODES))
+void render_tiles(KernArgs by_value) {
     __shared__ Lds<MODES> lds;
 #ifdef RTK_WAVE_ENDS
     const unsigned long long t_begin = wall_clock64();
 #endif
-    const SceneView sc = view_of(dsc, fr.segments);
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    for (uint32_t k = threadIdx.x; k < 128; k += blockDim.x) lds.disc[k] = fr.tbl_disc[k];
-    for (uint32_t k = threadIdx.x; k < 768; k += blockDim.x) lds.sphere[k] = fr.tbl_sphere[k];
-    if (lane < 4u) lds.ring[wave].left[lane] = 0u;
-    if (blockIdx.x == 0u && threadIdx.x == 0u) *fr.queue_next = 0u;     // the next launch starts at zero
-    if (MODES & 2) {
-        const RT_CONST_AS f4 *src = sc.tree_rec + (size_t)dsc.lds_first;
-        for (uint32_t k = threadIdx.x; k < dsc.lds_count; k += blockDim.x) lds.tree_top[k] = src[k];
+    // The arguments (90 dwords) are not kept in registers: with the loop's own wave-uniform
+    // state they would overflow the scalar register file, and the compiler's way out, parking
+    // them in lanes of a vector register, costs a vector instruction per use (a quarter of the
+    // vector instructions of a small scene).  Each part of the loop reads what it needs from the
+    // argument block in memory instead (scalar loads from a line that stays in the scalar cache),
+    // through a pointer the compiler cannot trace back (args()), so that the loads stay where
+    // they are written.
+    const RT_CONST_AS KernArgs *const args0 = (const RT_CONST_AS KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    auto args = [&]() { const RT_CONST_AS KernArgs *k = args0; asm volatile("" : "+s"(k)); return k; };
+    // (the wave's number as a scalar: what is indexed by it - its part of the staging ring, its
+    // rows in LDS - then has wave-uniform addresses that need no vector registers of their own)
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
+    {
+        const RT_CONST_AS KernArgs *k = args0;
+        for (uint32_t q = threadIdx.x; q < 128; q += blockDim.x) lds.disc[q] = k->fr.tbl_disc[q];
+        for (uint32_t q = threadIdx.x; q < 768; q += blockDim.x) lds.sphere[q] = k->fr.tbl_sphere[q];
+        if (lane < 4u) lds.ring[wave].left[lane] = 0u;
+        if (threadIdx.x == 0u) {
+            // width - 1, height - 1 and their refined reciprocals, for start_sample
+            const float w1 = (float)(k->p.width - 1u), h1 = (float)(k->p.height - 1u);
+            lds.uv[0] = w1; lds.uv[1] = h1; lds.uv[2] = rcp_refined(w1); lds.uv[3] = rcp_refined(h1);
+        }
+        if (blockIdx.x == 0u && threadIdx.x == 0u) *k->fr.queue_next = 0u;     // the next launch starts at zero
+        if (MODES & 2) {
+            const RT_CONST_AS f4 *src = const_ptr<f4>(k->dsc.tree_rec) + (size_t)k->dsc.lds_first;
+            for (uint32_t q = threadIdx.x; q < k->dsc.lds_count; q += blockDim.x) lds.tree_top[q] = src[q];
+        }
     }
     __syncthreads();
 
-    const uint32_t W = p.width, H = p.height;
-    const bool gamma = p.gamma != 0;
-    // see RayAux
-    const bool cheap_frame = RTK_SHORT_ARITH && dsc.cheap_ok != 0u && p.t_min >= 0x1p-20f;
-    // (column + disc entry) / (W - 1), src/raytracer.rs:255-256: the denominators are 1 .. 65535 and the
-    // numerators, for a table without tiny entries, zero-free and in 2^-90 .. 2^17
-    const bool cheap_uv = RTK_SHORT_ARITH && fr.disc_plain != 0u && W >= 2u && H >= 2u;
-    const float w1 = (float)(W - 1u), h1 = (float)(H - 1u);
-    const float inv_w1 = rcp_refined(w1), inv_h1 = rcp_refined(h1);
+    // what every part of the loop uses stays in registers
+    const uint32_t W = args0->p.width, H = args0->p.height;
+    const uint32_t unit_px_log2 = args0->unit_px_log2, sample_begin = args0->p.sample_begin;
+    const uint32_t max_bounces = args0->p.max_bounces;
     UnitRing &ring = lds.ring[wave];
     // this wave's part of the staging ring: DEV_STAGE_SLOTS units of up to 2^ITEM_BITS colours;
     // an item's place is its own number, ring slot << ITEM_BITS | index in the unit
-    StagedRgb *const stage = fr.stage + ((size_t)(blockIdx.x * waves_of(MODES) + wave) << (ITEM_BITS + 2u));
+    StagedRgb *const stage = args0->fr.stage + ((size_t)(blockIdx.x * waves_of(MODES) + wave) << (ITEM_BITS + 2u));
 
     // units of this launch: tile by tile along the band, the parts of a tile one after the other
-    const uint32_t tiles_x = (W + TILE - 1u) / TILE;
     const uint32_t unit_px = 1u << unit_px_log2;                  // 2 .. 64 pixels: part of a tile row, or whole rows
     const uint32_t unit_cols = unit_px < 8u ? unit_px : 8u, unit_rows = unit_px < 8u ? 1u : unit_px >> 3;
-    const uint32_t sub_log2 = 6u - unit_px_log2;                  // units per tile, log2
-    const uint32_t n_units = (tiles_x * n_bands) << sub_log2;
 
     // Per-lane state that lives across the scan is kept small (registers are what limits the
     // kernel): the work item, the ray, the depth budget and the unit-sphere counter.  Pixel,
@@ -1003,14 +1022,14 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
     bool alive = false;
     Ray ray;
     ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1);
-    uint32_t depth_left = p.max_bounces, path_counter = 0;
+    uint32_t depth_left = max_bounces, path_counter = 0;
     uint32_t n_seg = 0;
     // wave-uniform: the unit items are being handed out from
     uint32_t cur_slot = 3u, cur_next = 0u, cur_n = 0u;
     bool queue_empty = false;
     // the queue is read one unit ahead, so that the answer is there when it is needed
     uint32_t unit_ahead = 0u;
-    if (lane == 0u) unit_ahead = atomicAdd(fr.queue, 1u);
+    if (lane == 0u) unit_ahead = atomicAdd(args0->fr.queue, 1u);
 
     struct Where { uint32_t i, j, s; };      // column, row from the bottom, sample
     auto where = [&](uint32_t it) {
@@ -1019,41 +1038,49 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
         Where w;
         w.i = (xy & 0xffffu) + (q & (unit_cols - 1u));
         w.j = (xy >> 16) + ((q >> 3) & (unit_rows - 1u));
-        w.s = p.sample_begin + (q >> unit_px_log2);
+        w.s = sample_begin + (q >> unit_px_log2);
         return w;
     };
-    auto path_key_at = [&](const Where &w) { return mix32((w.j * W + w.i) ^ mix32(w.s ^ (p.seed * GOLDEN32))); };
+    auto path_key_at = [&](const Where &w, uint32_t seed) { return mix32((w.j * W + w.i) ^ mix32(w.s ^ (seed * GOLDEN32))); };
 
     auto start_sample = [&](const Where &w) {
+        const RT_CONST_AS KernArgs *k = args();
         // two disc draws per sample: jitter then lens (src/raytracer.rs:254,258);
         // sample n of a single-thread run uses entries 2n+1 and 2n+2 of the
         // pre-incremented counter (src/denoising/mod.rs:13-17)
         const uint32_t pix = w.j * W + w.i;
-        uint32_t n = pix * p.spp + w.s;   // only n mod 32 matters, wrap is harmless
+        uint32_t n = pix * k->p.spp + w.s;   // only n mod 32 matters, wrap is harmless
         uint32_t k1 = (2u * n + 1u) & 63u, k2 = (2u * n + 2u) & 63u;
         float ox = lds.disc[2 * k1], oy = lds.disc[2 * k1 + 1];
         float la = lds.disc[2 * k2], lb = lds.disc[2 * k2 + 1];
+        // (column + disc entry) / (W - 1), src/raytracer.rs:255-256: the denominators are 1 .. 65535 and the
+        // numerators, for a table without tiny entries, zero-free and in 2^-90 .. 2^17
+        const bool cheap_uv = RTK_SHORT_ARITH && k->fr.disc_plain != 0u && W >= 2u && H >= 2u;
+        const float w1 = lds.uv[0], h1 = lds.uv[1], inv_w1 = lds.uv[2], inv_h1 = lds.uv[3];
         float u, v;
         if (cheap_uv) { u = div_refined((float)w.i + ox, w1, inv_w1); v = div_refined((float)w.j + oy, h1, inv_h1); }
         else { u = ((float)w.i + ox) / w1; v = ((float)w.j + oy) / h1; }
-        ray = get_ray(cam, u, v, la, lb);
-        path_counter = path_key_at(w);
-        depth_left = p.max_bounces;
+        ray = get_ray(k->cam, u, v, la, lb);
+        path_counter = path_key_at(w, k->p.seed);
+        depth_left = max_bounces;
     };
 
     // All items of the unit in `slot` are finished and their colours stored (by lanes of
     // this wave): its pixels are added up, one pixel per lane.
     auto finish_unit = [&](uint32_t slot) {
+        const RT_CONST_AS KernArgs *k = args();
+        float4 *const accum = k->fr.accum;
+        const uint32_t sample_count = k->p.sample_count;
         const uint32_t xy = ring.xy[slot];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // the unit's pixel number `lane` (see where()): column lane % 8, row lane / 8
         const uint32_t pi = (xy & 0xffffu) + (lane & 7u), pj = (xy >> 16) + (lane >> 3);
         if (lane < unit_px && pi < W && pj < H) {
             const size_t pix_out = (size_t)(H - 1u - pj) * W + pi;   // src/raytracer.rs:265
-            float4 acc = fr.accum[pix_out];
+            float4 acc = accum[pix_out];
             V3 px = mk(acc.x, acc.y, acc.z);
             // with a depth budget of 0 every sample is black and nothing was traced
-            const uint32_t n_add = p.max_bounces > 0 ? p.sample_count : 0u;
+            const uint32_t n_add = max_bounces > 0 ? sample_count : 0u;
             // sample k of the unit's pixel `lane` is item lane + pixels of the unit * k
             const StagedRgb *src = stage + ((slot << ITEM_BITS) | lane);
             uint32_t k = 0;
@@ -1069,7 +1096,7 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
                 const StagedRgb c = src[(size_t)k << unit_px_log2];
                 px = px + mk(c.r, c.g, c.b);
             }
-            fr.accum[pix_out] = make_float4(px.x, px.y, px.z, acc.w + (float)p.sample_count);
+            accum[pix_out] = make_float4(px.x, px.y, px.z, acc.w + (float)sample_count);
         }
     };
 
@@ -1084,20 +1111,25 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
                 if (queue_empty) break;
                 const uint32_t slot = (cur_slot + 1u) & 3u;
                 if (ring.left[slot] != 0u) break;
+                const RT_CONST_AS KernArgs *k = args();
+                const uint32_t tiles_x = (W + TILE - 1u) / TILE;
+                const uint32_t sub_log2 = 6u - unit_px_log2;                  // units per tile, log2
+                const uint32_t n_units = (tiles_x * k->n_bands) << sub_log2;
+                const uint32_t sample_count = k->p.sample_count;
                 const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit_ahead);
                 if (u >= n_units) { queue_empty = true; break; }
-                if (lane == 0u) unit_ahead = atomicAdd(fr.queue, 1u);
+                if (lane == 0u) unit_ahead = atomicAdd(k->fr.queue, 1u);
                 const uint32_t t = u >> sub_log2, sub = u & ((1u << sub_log2) - 1u);
                 const uint32_t by = t / tiles_x, tx = t - by * tiles_x;
-                const uint32_t band = p.band_begin + by * p.band_stride;
+                const uint32_t band = k->p.band_begin + by * k->p.band_stride;
                 const uint32_t first = sub << unit_px_log2;                 // the unit's first pixel of the tile, row-major
                 const uint32_t x0 = tx * TILE + (first & 7u), y0 = band * TILE + (first >> 3);
                 const uint32_t vw = x0 >= W ? 0u : (W - x0 < unit_cols ? W - x0 : unit_cols);
                 const uint32_t vh = y0 >= H ? 0u : (H - y0 < unit_rows ? H - y0 : unit_rows);
-                const uint32_t left = p.max_bounces > 0u ? vw * vh * p.sample_count : 0u;
+                const uint32_t left = max_bounces > 0u ? vw * vh * sample_count : 0u;
                 if (lane == 0u) { ring.xy[slot] = x0 | (y0 << 16); ring.left[slot] = left; }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                cur_slot = slot; cur_next = 0u; cur_n = p.max_bounces > 0u ? p.sample_count << unit_px_log2 : 0u;
+                cur_slot = slot; cur_next = 0u; cur_n = max_bounces > 0u ? sample_count << unit_px_log2 : 0u;
                 if (left == 0u) { finish_unit(slot); continue; }
             }
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -1120,7 +1152,11 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
 #ifdef RTK_TIMES
         const unsigned long long tm0 = __builtin_readcyclecounter();
 #endif
+        const RT_CONST_AS KernArgs *k = args();
+        const SceneView sc = view_of(k->dsc, k->fr.segments);
+        const float t_min = k->p.t_min;
         // |direction|^2 and whether the short division and root sequences apply (see RayAux)
+        const bool cheap_frame = RTK_SHORT_ARITH && k->dsc.cheap_ok != 0u && t_min >= 0x1p-20f;
         RayAux aux;
         aux.a = len2(ray.d);
         {
@@ -1129,7 +1165,7 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
             aux.cheap = cheap_frame && __builtin_amdgcn_ballot_w64(alive && !moderate) == 0ull;
             aux.inv_a = rcp_refined(aux.a);
         }
-        scan_list<MODES>(sc, ray, aux, p.t_min, alive, lds.tree[wave], lds.tree_top, h);
+        scan_list<MODES>(sc, ray, aux, t_min, alive, lds.tree[wave], lds.tree_top, h);
 #ifdef RTK_TIMES
         const unsigned long long tm1 = __builtin_readcyclecounter();
         tm_scan += tm1 - tm0;
@@ -1137,12 +1173,15 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
         n_seg += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(alive));
         bool done = false;
         if (alive) {
+            // (the arguments the shading needs are read after the scan, not kept across it)
+            const RT_CONST_AS KernArgs *ks = args();
+            const SceneView sc = view_of(ks->dsc, ks->fr.segments);
             const Where at = where(item);
-            const uint32_t n_stack = p.max_bounces - depth_left;   // hits of this path so far
+            const uint32_t n_stack = max_bounces - depth_left;   // hits of this path so far
             const size_t pix_out = (size_t)(H - 1u - at.j) * W + at.i;   // src/raytracer.rs:265
             // BlueNoise::get_screenspace, src/denoising/mod.rs:19-23: fixed per pixel
-            const float sp_bn = fr.tbl_screen[128u * (at.i % 128u) + (at.j % 128u)];
-            if (at.s == 0u && n_stack == 0u) fr.primary_ids[pix_out] = h.id;
+            const float sp_bn = ks->fr.tbl_screen[128u * (at.i % 128u) + (at.j % 128u)];
+            if (at.s == 0u && n_stack == 0u) ks->fr.primary_ids[pix_out] = h.id;
             // unit_vector(direction): the sky (src/raytracer.rs:82), Metal and Dielectric all start
             // from it; computed once for the wave instead of once per branch
             // (cheap: 2^-12 <= |d| <= 2^12, every component at most that)
@@ -1150,14 +1189,14 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
             V3 c;
             uint32_t n_hits = n_stack;
             if (h.kind >= 0) {
-                uint32_t mat = shade_hit(sc, lds.sphere, ray, ud, h, aux.cheap, sp_bn, path_counter, path_key_at(at), n_stack);
+                uint32_t mat = shade_hit(sc, lds.sphere, ray, ud, h, aux.cheap, sp_bn, path_counter, path_key_at(at, ks->p.seed), n_stack);
                 lds.mat_stack[wave][n_stack][lane] = mat;
                 n_hits = n_stack + 1u;
                 depth_left -= 1;
                 done = depth_left == 0u;   // `if ray_bounces <= 0 { return 0 }`, src/raytracer.rs:69
                 c = mk(0.0f, 0.0f, 0.0f);
             } else {
-                c = sky(ud, gamma);
+                c = sky(ud, ks->p.gamma != 0u);
                 done = true;
             }
 #ifdef RTK_TIMES
@@ -1214,9 +1253,10 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
 #ifdef RTK_TIMES
     // development aid: wave time inside the closest-hit scan and outside it
     if (lane == 0) {
-        atomicAdd(fr.segments + 4, tm_scan); atomicAdd(fr.segments + 7, tm_rest);
-        atomicAdd(fr.segments + 5, tm_done); atomicAdd(fr.segments + 6, tm_fetch);
-        atomicAdd(fr.segments + 3, tm_fin);
+        unsigned long long *const seg = args0->fr.segments;
+        atomicAdd(seg + 4, tm_scan); atomicAdd(seg + 7, tm_rest);
+        atomicAdd(seg + 5, tm_done); atomicAdd(seg + 6, tm_fetch);
+        atomicAdd(seg + 3, tm_fin);
     }
 #endif
 #ifdef RTK_WAVE_ENDS
@@ -1227,7 +1267,7 @@ void render_tiles(DevScene dsc, rt_camera cam, rt_params p, DevFrame fr, uint32_
         log[0] = t_begin | ((unsigned long long)n_seg << 40); log[1] = wall_clock64();
     }
 #endif
-    if (lane == 0 && n_seg != 0) atomicAdd(fr.segments, (unsigned long long)n_seg);
+    if (lane == 0 && n_seg != 0) atomicAdd(args0->fr.segments, (unsigned long long)n_seg);
 }
 
 // write_colour + from_u8_rgb, src/raytracer.rs:35-55
@@ -1359,7 +1399,7 @@ hipError_t rtk_launch_pack_bands(const float4 *accum, uint32_t *out, uint32_t W,
                        n_bands);
     return hipGetLastError();
 }
-uint32_t rtk_resident_waves(uint32_t n_cus) { return n_cus * 4u * RTK_OCC; }
+uint32_t rtk_resident_waves(uint32_t n_cus) { return n_cus * 4u * (RTK_OCC > RTK_OCC0 ? RTK_OCC : RTK_OCC0); }
 hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_params &p,
                              const DevFrame &fr, uint32_t n_bands, uint32_t n_cus, uint32_t stage_waves,
                              int unit_px_log2, hipStream_t stream) {
@@ -1367,7 +1407,7 @@ hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_
     const uint32_t tiles_x = (p.width + rtk::TILE - 1u) / rtk::TILE;
     const uint64_t n_tiles = (uint64_t)tiles_x * n_bands;
     // workgroups the chip holds at once, and the staging ring has room for
-    const uint64_t resident = std::min<uint64_t>((uint64_t)n_cus * (4u * RTK_OCC / waves), stage_waves / waves);
+    const uint64_t resident = std::min<uint64_t>((uint64_t)n_cus * (4u * rtk::occ_of((int)(sc.modes & 3u)) / waves), stage_waves / waves);
     if (p.sample_count > DEV_SAMPLE_CHUNK || p.width > 65536u || p.height > 65536u || resident == 0u) return hipErrorInvalidValue;
     const uint64_t max_items = 1ull << DEV_STAGE_ITEM_BITS;    // a unit's colours must fit one ring slot
     // Pixels of a tile per work unit (part of a row, or whole rows): the fewest that still give a
@@ -1390,11 +1430,12 @@ hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_
     const uint64_t groups = std::max<uint64_t>(1u, std::min<uint64_t>(resident, (n_units + waves - 1u) / waves));
     dim3 grid((uint32_t)groups, 1, 1), block(waves * 64, 1, 1);
     const uint32_t r = (uint32_t)unit_px_log2;
+    const rtk::KernArgs ka{sc, cam, p, fr, n_bands, r};
     switch (sc.modes & 3u) {
-    case 0: hipLaunchKernelGGL(rtk::render_tiles<0>, grid, block, 0, stream, sc, cam, p, fr, n_bands, r); break;
-    case 1: hipLaunchKernelGGL(rtk::render_tiles<1>, grid, block, 0, stream, sc, cam, p, fr, n_bands, r); break;
-    case 2: hipLaunchKernelGGL(rtk::render_tiles<2>, grid, block, 0, stream, sc, cam, p, fr, n_bands, r); break;
-    default: hipLaunchKernelGGL(rtk::render_tiles<3>, grid, block, 0, stream, sc, cam, p, fr, n_bands, r); break;
+    case 0: hipLaunchKernelGGL(rtk::render_tiles<0>, grid, block, 0, stream, ka); break;
+    case 1: hipLaunchKernelGGL(rtk::render_tiles<1>, grid, block, 0, stream, ka); break;
+    case 2: hipLaunchKernelGGL(rtk::render_tiles<2>, grid, block, 0, stream, ka); break;
+    default: hipLaunchKernelGGL(rtk::render_tiles<3>, grid, block, 0, stream, ka); break;
     }
     return hipGetLastError();
 }
