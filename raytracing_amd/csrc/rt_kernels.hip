@@ -225,7 +225,10 @@ template <int MODES>
 struct Lds {
     float disc[128];                                    // src/denoising/mod.rs:55
     float sphere[768];                                  // src/denoising/mod.rs:59
-    uint32_t mat_stack[waves_of(MODES)][RT_MAX_BOUNCES][64];
+#ifndef RTK_STACK_DEPTH
+#define RTK_STACK_DEPTH RT_MAX_BOUNCES
+#endif
+    uint32_t mat_stack[waves_of(MODES)][RTK_STACK_DEPTH][64];
     TreeTable tree[waves_of(MODES)];                    // per-level constants of the run being walked
     UnitRing ring[waves_of(MODES)];                     // the units each wave has in flight
     float uv[4];                                        // width - 1, height - 1, their refined reciprocals
