@@ -206,12 +206,6 @@ constexpr int TILE = 8;   // 8x8 pixels per wavefront
 struct TreeTable {
     uint32_t base[DEV_MAX_LEVELS];    // float4 offset of each level in tree_rec
     uint32_t count[DEV_MAX_LEVELS];   // boxes at each level
-    // closest-hit state of every lane when it entered the run being walked, for the lanes
-    // that have to start the run over in list order
-    float entry_t[64];
-    int32_t entry_id[64];
-    uint32_t entry_slot[64];
-    uint32_t entry_bits[64];   // kind + 1 | ff << 8 | ff_shared << 9
 };
 
 // The work units a wave has in flight (see render_tiles): column | row << 16 of the unit's first
@@ -302,15 +296,9 @@ struct Hit {
 // an equal-distance candidate with a smaller list position than the current
 // holder is refused here.  In a list-order scan positions only grow and the
 // extra condition never fires.
+// The decision functions ask for list positions through callbacks, only when two distances
+// tie: a list-order scan knows them, the tree walk reads them from the by-slot tables.
 // ----------------------------------------------------------------------
-// The tree walk does not look up the list position of every primitive it tests: it passes
-// ID_LATER, and the position is read from the by-slot table only when two hit distances tie
-// and, once, for the hit the run ends with.  (An ID_LATER holder is always a primitive of the
-// kind and run being walked: earlier runs leave real positions.)
-#define ID_LATER (-2)
-__device__ __forceinline__ int32_t list_position(const RT_CONST_AS uint32_t *by_slot, uint32_t slot, int32_t id) {
-    return id == ID_LATER ? (int32_t)by_slot[slot] : id;
-}
 // What the exact tests need to know about the ray beyond origin and direction: `a` is |dir|^2
 // (Sphere::hit, src/geometry/mod.rs:63, the same for every sphere).  `cheap` is wave-uniform and
 // says that every ray being traced has 2^-24 <= a <= 2^24 and |origin coordinates| <= 2^30, every
@@ -319,40 +307,51 @@ __device__ __forceinline__ int32_t list_position(const RT_CONST_AS uint32_t *by_
 // below 2^60; one below 2^-90 gives a root below 2^-66, which both this and `/` put in front of
 // t_min, so its bits are never looked at.)
 struct RayAux { float a, inv_a; bool cheap; };
-// Sphere::hit, src/geometry/mod.rs:60-94
-// (nan_out, where given, is set when the accepted distance is NaN)
-__device__ __forceinline__ void sphere_exact(const SceneView &sc, uint32_t slot, int32_t id, const Ray &ray,
-                                             const RayAux &aux, float t_min, Hit &h, bool &ff_shared, bool *nan_out = nullptr) {
+// Sphere::hit, src/geometry/mod.rs:60-94, up to the decision: true, with the hit distance in
+// `root`, when the sphere in `slot` replaces a holder at distance `closest`.  this_pos() and
+// holder_pos() give the list positions of the two, asked for only when the distances tie.
+template <class ThisPos, class HolderPos>
+__device__ __forceinline__ bool sphere_closer(const SceneView &sc, uint32_t slot, const Ray &ray, const RayAux &aux,
+                                              float t_min, float closest, ThisPos this_pos, HolderPos holder_pos,
+                                              float &root) {
     const float a = aux.a;
     const f4 g = sc.sph_geom[slot];   // cx, cy, cz, radius
     V3 oc = ray.o - mk(g.x, g.y, g.z);
     float half_b = dot(oc, ray.d);
     float c = len2(oc) - g.w * g.w;
     float disc = half_b * half_b - a * c;
-    if (disc < 0.0f) return;
-    float root;
+    if (disc < 0.0f) return false;
     float d_sqrt = sqrt_mostly(disc);
     if (aux.cheap) {
         root = div_refined(-(half_b + d_sqrt), a, aux.inv_a);
-        if (root < t_min || h.t < root) {
+        if (root < t_min || closest < root) {
             root = div_refined(-half_b + d_sqrt, a, aux.inv_a);
-            if (root < t_min || h.t < root) return;
+            if (root < t_min || closest < root) return false;
         }
     } else {
         root = -(half_b + d_sqrt) / a;
-        if (root < t_min || h.t < root) {
+        if (root < t_min || closest < root) {
             root = (-half_b + d_sqrt) / a;
-            if (root < t_min || h.t < root) return;
+            if (root < t_min || closest < root) return false;
         }
     }
-    if (root == h.t && list_position(sc.sph_id, slot, id) < list_position(sc.sph_id, h.slot, h.id)) return;
+    if (root == closest && this_pos() < holder_pos()) return false;
+    return true;
+}
+// front_face of a sphere hit at distance t, src/geometry/mod.rs:81-86,30-33
+__device__ __forceinline__ bool sphere_front_face(const SceneView &sc, uint32_t slot, const Ray &ray, float t, bool cheap) {
+    const f4 g = sc.sph_geom[slot];
+    V3 p = ray.o + ray.d * t;
+    V3 outward = div3(p - mk(g.x, g.y, g.z), g.w, cheap);
+    return dot(ray.d, outward) < 0.0f;
+}
+// one sphere of a list-order scan
+__device__ __forceinline__ void sphere_exact(const SceneView &sc, uint32_t slot, int32_t id, const Ray &ray,
+                                             const RayAux &aux, float t_min, Hit &h, bool &ff_shared) {
+    float root;
+    if (!sphere_closer(sc, slot, ray, aux, t_min, h.t, [&]() { return id; }, [&]() { return h.id; }, root)) return;
     h.t = root; h.kind = DEV_SPHERE; h.slot = slot; h.id = id;
-    if (nan_out) *nan_out = root != root;
-    if (sc.need_ff_shared) {
-        V3 p = ray.o + ray.d * root;
-        V3 outward = div3(p - mk(g.x, g.y, g.z), g.w, aux.cheap);
-        ff_shared = dot(ray.d, outward) < 0.0f;
-    }
+    if (sc.need_ff_shared) ff_shared = sphere_front_face(sc, slot, ray, root, aux.cheap);
 }
 // same selections as `m = a > b ? a : b; m > c ? m : c` (and < for min): with a NaN operand the
 // results may differ from a fused max3, so they are spelled out
@@ -361,8 +360,9 @@ __device__ __forceinline__ float min3(float a, float b, float c) { float m = a <
 // Triangle (defined by rt_hip.h, absent from the reference): Moller-Trumbore, then the
 // bounding-box gate that keeps the f32 barycentric test from accepting points far outside
 // a sliver or an edge-on triangle
-__device__ __forceinline__ void tri_exact(const SceneView &sc, uint32_t slot, int32_t id, const Ray &ray,
-                                          float t_min, Hit &h, bool &ff_shared, bool *nan_out = nullptr) {
+template <class ThisPos, class HolderPos>
+__device__ __forceinline__ bool tri_closer(const SceneView &sc, uint32_t slot, const Ray &ray, float t_min, float closest,
+                                           ThisPos this_pos, HolderPos holder_pos, float &t) {
     const f4 v0 = sc.tris[3 * slot];
     const f4 e1 = sc.tris[3 * slot + 1];
     const f4 e2 = sc.tris[3 * slot + 2];
@@ -372,16 +372,16 @@ __device__ __forceinline__ void tri_exact(const SceneView &sc, uint32_t slot, in
     V3 E1 = mk(e1.x, e1.y, e1.z), E2 = mk(e2.x, e2.y, e2.z);
     V3 hh = cross(ray.d, E2);
     float det = dot(E1, hh);
-    if (det == 0.0f) return;
+    if (det == 0.0f) return false;
     float f = 1.0f / det;
     V3 s = ray.o - mk(v0.x, v0.y, v0.z);
     float u = f * dot(s, hh);
-    if (u < 0.0f || u > 1.0f) return;
+    if (u < 0.0f || u > 1.0f) return false;
     V3 q = cross(s, E1);
     float v = f * dot(ray.d, q);
-    if (v < 0.0f || u + v > 1.0f) return;
-    float t = f * dot(E2, q);
-    if (t < t_min || h.t < t) return;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    t = f * dot(E2, q);
+    if (t < t_min || closest < t) return false;
     // gate: the hit point must lie in the widened bounding box of the triangle
     {
         const V3 a0 = mk(v0.x, v0.y, v0.z), a1 = a0 + E1, a2 = a0 + E2, p = ray.o + ray.d * t;
@@ -393,15 +393,25 @@ __device__ __forceinline__ void tri_exact(const SceneView &sc, uint32_t slot, in
                                max3(__builtin_fabsf(ray.o.x), __builtin_fabsf(ray.o.y), __builtin_fabsf(ray.o.z)));
         const float delta = ext * 0.0078125f + mag * 9.5367431640625e-07f;
         if (!(p.x >= lo.x - delta && p.x <= hi.x + delta && p.y >= lo.y - delta && p.y <= hi.y + delta &&
-              p.z >= lo.z - delta && p.z <= hi.z + delta)) return;
+              p.z >= lo.z - delta && p.z <= hi.z + delta)) return false;
     }
-    if (t == h.t && list_position(sc.tri_id, slot, id) < list_position(sc.tri_id, h.slot, h.id)) return;
+    if (t == closest && this_pos() < holder_pos()) return false;
+    return true;
+}
+// front_face of a triangle hit: outward normal unit(cross(e1, e2))
+__device__ __forceinline__ bool tri_front_face(const SceneView &sc, uint32_t slot, const Ray &ray) {
+    const f4 e1 = sc.tris[3 * slot + 1];
+    const f4 e2 = sc.tris[3 * slot + 2];
+    V3 outward = unit(cross(mk(e1.x, e1.y, e1.z), mk(e2.x, e2.y, e2.z)));
+    return dot(ray.d, outward) < 0.0f;
+}
+// one triangle of a list-order scan
+__device__ __forceinline__ void tri_exact(const SceneView &sc, uint32_t slot, int32_t id, const Ray &ray,
+                                          float t_min, Hit &h, bool &ff_shared) {
+    float t;
+    if (!tri_closer(sc, slot, ray, t_min, h.t, [&]() { return id; }, [&]() { return h.id; }, t)) return;
     h.t = t; h.kind = DEV_TRI; h.slot = slot; h.id = id;
-    if (nan_out) *nan_out = t != t;
-    if (sc.need_ff_shared) {
-        V3 outward = unit(cross(E1, E2));
-        ff_shared = dot(ray.d, outward) < 0.0f;
-    }
+    if (sc.need_ff_shared) ff_shared = tri_front_face(sc, slot, ray);
 }
 
 // ----------------------------------------------------------------------
@@ -566,10 +576,25 @@ __device__ __forceinline__ void scan_flat(const SceneView &sc, const RunView &ru
 //       ulp of S.  2^-17 S covers (b) and the triangles' (a) three times over.
 // A lane leaves the walk as soon as its closest_so_far turns NaN (see scan_tree).
 // ----------------------------------------------------------------------
+// The walk keeps the closest hit so far as a distance and a slot of the run (NO_SLOT: still
+// the hit the ray came with, at list position entry_pos); the hit record is written once, after
+// the walk.  Exact test of the primitive in `slot` against that state.
+constexpr uint32_t NO_SLOT = 0xffffffffu;
+template <int KIND>
+__device__ __forceinline__ bool walk_test(const SceneView &sc, uint32_t slot, const Ray &ray, const RayAux &aux,
+                                          float t_min, int32_t entry_pos, float best_t, uint32_t best_slot, float &t) {
+    const RT_CONST_AS uint32_t *by_slot = KIND == DEV_SPHERE ? sc.sph_id : sc.tri_id;
+    auto this_pos = [&]() { return (int32_t)by_slot[slot]; };
+    auto holder_pos = [&]() { return best_slot == NO_SLOT ? entry_pos : (int32_t)by_slot[best_slot]; };
+    if (KIND == DEV_SPHERE) return sphere_closer(sc, slot, ray, aux, t_min, best_t, this_pos, holder_pos, t);
+    return tri_closer(sc, slot, ray, t_min, best_t, this_pos, holder_pos, t);
+}
+
 template <int KIND>
 __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &run, bool walking,
                                           TreeTable &tbl, const f4 *tree_top, uint32_t lds_from_level,
-                                          const Ray &ray, const RayAux &aux, float t_min, Hit &h, bool &ff_shared) {
+                                          const Ray &ray, const RayAux &aux, float t_min, int32_t entry_pos,
+                                          float &best_t, uint32_t &best_slot) {
     // per-level constants where a lane can index them by its own level
 #pragma unroll
     for (uint32_t L = 0; L < DEV_MAX_LEVELS; ++L) { tbl.base[L] = run.lo[8 + L]; tbl.count[L] = run.hi[L]; }
@@ -601,10 +626,16 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
         uint32_t L = top, st = ts;
         unsigned long long pend = 0ull;
         bool act = walking;
+#ifdef RTK_STATS
         while (__builtin_amdgcn_ballot_w64(act) != 0ull) {
             RTK_COUNT(sc, 2, 1);
             RTK_COUNT(sc, 5, __builtin_popcountll(__builtin_amdgcn_ballot_w64(act)));
             if (act) {
+#else
+        // (a lane leaves the loop when it has no node left; the wave goes on while any lane is inside)
+        while (act) {
+            {
+#endif
                 const uint32_t at = tbl.base[L] + 12u * st;
                 f4 nd[12];
                 if (L >= lds_from_level) {
@@ -637,7 +668,7 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
                         // point and stay together through the other slabs.  A box is kept only if
                         // enter < leave; an interval of length zero is at most a touch of the widened
                         // box, which no primitive inside reaches.
-                        float enter = t_low, leave = h.t;
+                        float enter = t_low, leave = best_t;
                         enter = __builtin_amdgcn_fmed3f(ax_, bx_, enter); leave = __builtin_amdgcn_fmed3f(ax_, bx_, leave);
                         enter = __builtin_amdgcn_fmed3f(ay_, by_, enter); leave = __builtin_amdgcn_fmed3f(ay_, by_, leave);
                         enter = __builtin_amdgcn_fmed3f(az_, bz_, enter); leave = __builtin_amdgcn_fmed3f(az_, bz_, leave);
@@ -674,12 +705,15 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
                         const uint32_t slot = run.first + 8u * st + k;
                         RTK_COUNT(sc, 4, 1);
                         RTK_COUNT_ANY(sc, 7, 1);
-                        if (KIND == DEV_SPHERE) sphere_exact(sc, slot, ID_LATER, ray, aux, t_min, h, ff_shared, &got_nan);
-                        else tri_exact(sc, slot, ID_LATER, ray, t_min, h, ff_shared, &got_nan);
+                        float t;
+                        const bool closer = walk_test<KIND>(sc, slot, ray, aux, t_min, entry_pos, best_t, best_slot, t);
+                        best_t = closer ? t : best_t;
+                        best_slot = closer ? slot : best_slot;
+                        got_nan = closer && t != t;
                     }
                     // next pending sibling, of this node or of its nearest ancestor that has one
                     const unsigned long long rest = pend >> (8u * L);
-                    if (rest == 0ull || h.t != h.t) {
+                    if (rest == 0ull || best_t != best_t) {
                         act = false;
                     } else {
                         const uint32_t z = (uint32_t)__builtin_ctzll(rest);
@@ -711,34 +745,37 @@ __device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &ru
                                           const Ray &ray, const RayAux &aux, float t_min, Hit &h, bool &ff_shared) {
     const float big = 1e18f;
     const float a = aux.a;
-    const uint32_t lane = threadIdx.x & 63u;
     const bool tame = a > 1e-12f && a < 1e12f && h.t == h.t &&
                       __builtin_fabsf(ray.o.x) < big && __builtin_fabsf(ray.o.y) < big && __builtin_fabsf(ray.o.z) < big;
     const bool walking = tracing && tame;
     bool listed = tracing && !tame;   // lanes that take the run in list order
     if (__builtin_amdgcn_ballot_w64(walking) != 0ull) {
-        if (walking) {
-            tbl.entry_t[lane] = h.t;
-            tbl.entry_id[lane] = h.id;
-            tbl.entry_slot[lane] = h.slot;
-            tbl.entry_bits[lane] = (uint32_t)(h.kind + 1) | ((uint32_t)h.ff << 8) | ((uint32_t)ff_shared << 9);
-        }
+        // the hit record stays as the ray came with it until the walk is over (a lane that has to
+        // start the run over in list order starts from it)
+        float best_t = h.t;
+        uint32_t best_slot = NO_SLOT;
         // primitives the tree does not hold (non-finite or huge coordinates): every ray tests them
         const uint32_t n_unbounded = run.hi[10];
         for (uint32_t k = 0; k < n_unbounded; ++k) {
             const uint32_t slot = run.first + sc.order[run.order_base + run.count + k];
-            if (walking && h.t == h.t) {
-                if (KIND == DEV_SPHERE) sphere_exact(sc, slot, ID_LATER, ray, aux, t_min, h, ff_shared);
-                else tri_exact(sc, slot, ID_LATER, ray, t_min, h, ff_shared);
+            if (walking && best_t == best_t) {
+                float t;
+                const bool closer = walk_test<KIND>(sc, slot, ray, aux, t_min, h.id, best_t, best_slot, t);
+                best_t = closer ? t : best_t;
+                best_slot = closer ? slot : best_slot;
             }
         }
-        walk_tree<KIND>(sc, run, walking && h.t == h.t, tbl, tree_top, lds_from_level, ray, aux, t_min, h, ff_shared);
-        if (walking && h.id == ID_LATER) h.id = (int32_t)(KIND == DEV_SPHERE ? sc.sph_id[h.slot] : sc.tri_id[h.slot]);
-        if (walking && h.t != h.t) {
-            const uint32_t bits = tbl.entry_bits[lane];
-            h.t = tbl.entry_t[lane]; h.id = tbl.entry_id[lane]; h.slot = tbl.entry_slot[lane];
-            h.kind = (int)(bits & 0xffu) - 1; h.ff = (bits >> 8) & 1u; ff_shared = (bits >> 9) & 1u;
+        walk_tree<KIND>(sc, run, walking && best_t == best_t, tbl, tree_top, lds_from_level, ray, aux, t_min, h.id,
+                        best_t, best_slot);
+        if (walking && best_t != best_t) {
             listed = true;
+        } else if (walking && best_slot != NO_SLOT) {
+            h.t = best_t; h.kind = KIND; h.slot = best_slot;
+            h.id = (int32_t)(KIND == DEV_SPHERE ? sc.sph_id[best_slot] : sc.tri_id[best_slot]);
+            // temp_hr.front_face as the last accepted primitive of the run left it: the run's closest
+            if (sc.need_ff_shared)
+                ff_shared = KIND == DEV_SPHERE ? sphere_front_face(sc, best_slot, ray, best_t, aux.cheap)
+                                               : tri_front_face(sc, best_slot, ray);
         }
     }
     if (__builtin_amdgcn_ballot_w64(listed) != 0ull) {
