@@ -27,9 +27,9 @@
 
 #include "rt_device.h"
 
-#ifndef RTK_SUM_BATCH
-#define RTK_SUM_BATCH 16u    // staged colours fetched at a time when a unit is added up
-#endif
+// staged colours fetched at a time when a unit is added up: 16 where the tree walk sets the kernel's
+// vector register count anyway, 8 elsewhere (with 16 this rare step set it: 96 registers instead of 64)
+__host__ __device__ constexpr uint32_t sum_batch_of(int modes) { return (modes & 2) ? 16u : 8u; }
 static_assert(DEV_STAGE_SLOTS == 4u, "UnitRing and the slot arithmetic assume four units in flight per wave");
 #ifndef RTK_TREE_WAVES
 #define RTK_TREE_WAVES 8
@@ -198,8 +198,8 @@ __host__ __device__ constexpr int waves_of(int modes) { return (modes & 2) ? RTK
 #define RTK_OCC 4
 #endif
 #ifndef RTK_OCC0
-#define RTK_OCC0 5           // scenes without long runs: 92 VGPRs, no spills (six waves spill 20; measured on the
-#endif                       // default scene at 1080p, 64 samples: 6.61 ms with four waves per SIMD, 5.92 with five, 6.98 with six)
+#define RTK_OCC0 8           // scenes without long runs: 64 VGPRs, no spills.  Default scene at 1080p, 64 samples:
+#endif                       // 6.40 ms with four waves per SIMD, 5.70 with five, 5.48 with six and with eight
 __host__ __device__ constexpr int occ_of(int modes) { return modes == 0 ? RTK_OCC0 : RTK_OCC; }
 constexpr int TILE = 8;   // 8x8 pixels per wavefront
 
@@ -1122,18 +1122,19 @@ void render_tiles(KernArgs by_value) {
             // with a depth budget of 0 every sample is black and nothing was traced
             const uint32_t n_add = max_bounces > 0 ? sample_count : 0u;
             // sample k of the unit's pixel `lane` is item lane + pixels of the unit * k
-            const StagedRgb *src = stage + ((slot << ITEM_BITS) | lane);
+            // (a wave-uniform base and a 32-bit index: the items of a ring slot number 512 at most)
+            const StagedRgb *src = stage + (slot << ITEM_BITS);
             uint32_t k = 0;
-            // RTK_SUM_BATCH loads on the way at a time; the additions keep their order (src/raytracer.rs:262)
-            for (; k + RTK_SUM_BATCH <= n_add; k += RTK_SUM_BATCH) {
-                StagedRgb c[RTK_SUM_BATCH];
+            // sum_batch_of(MODES) loads on the way at a time; the additions keep their order (src/raytracer.rs:262)
+            for (; k + sum_batch_of(MODES) <= n_add; k += sum_batch_of(MODES)) {
+                StagedRgb c[sum_batch_of(MODES)];
 #pragma unroll
-                for (uint32_t m = 0; m < RTK_SUM_BATCH; ++m) c[m] = src[(size_t)(k + m) << unit_px_log2];
+                for (uint32_t m = 0; m < sum_batch_of(MODES); ++m) c[m] = src[lane + ((k + m) << unit_px_log2)];
 #pragma unroll
-                for (uint32_t m = 0; m < RTK_SUM_BATCH; ++m) px = px + mk(c[m].r, c[m].g, c[m].b);
+                for (uint32_t m = 0; m < sum_batch_of(MODES); ++m) px = px + mk(c[m].r, c[m].g, c[m].b);
             }
             for (; k < n_add; ++k) {
-                const StagedRgb c = src[(size_t)k << unit_px_log2];
+                const StagedRgb c = src[lane + (k << unit_px_log2)];
                 px = px + mk(c.r, c.g, c.b);
             }
             accum[pix_out] = make_float4(px.x, px.y, px.z, acc.w + (float)sample_count);
@@ -1459,8 +1460,11 @@ hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_
         unit_px_log2 = 3;
         while (unit_px_log2 < 6 && ((uint64_t)p.sample_count << (unit_px_log2 + 1)) <= max_items) ++unit_px_log2;
         // a small launch (one GPU's share of a frame): half as long units, so that a wave still
-        // gets a few dozen of them
-        if ((n_tiles << (6 - unit_px_log2)) < 48u * resident * waves && ((uint64_t)p.sample_count << unit_px_log2) >= 512u)
+        // gets a few dozen of them.  Scenes without a tree have short segments and feel the cost of
+        // a unit more (default scene, whole 1080p frame at 64 samples: 7.0 ms with 256-item units,
+        // 5.7 with 512), so there units are halved only below two dozen per wave.
+        const uint64_t want = (sc.modes & 2u) ? 48u : 24u;
+        if ((n_tiles << (6 - unit_px_log2)) < want * resident * waves && ((uint64_t)p.sample_count << unit_px_log2) >= 512u)
             --unit_px_log2;
     }
     if (((uint64_t)p.sample_count << unit_px_log2) > max_items) return hipErrorInvalidValue;

@@ -23,8 +23,9 @@ assert r._lib.rtdbg_read_counters(r._ctx, out) == 0
 names = ["segments", "wave_scans", "box_trips", "leaf_trips", "exact_lane0", "box_lane_visits", "leaf_lane_visits", "exact_wave_iters"]
 v = list(out)
 print("ms", round(ms, 2), dict(zip(names, v)))
-if v[1] and v[5]:
+if v[1]:
     print("lane utilisation %.3f" % (v[0] / (64.0 * v[1])))
+if v[1] and v[5]:
     print("per wave-scan: box trips %.1f (lanes busy %.1f), leaf trips %.1f (lanes busy %.1f), exact-loop iterations %.1f"
           % (v[2] / v[1], v[5] / max(1, v[2]), v[3] / v[1], v[6] / max(1, v[3]), v[7] / v[1]))
     print("per ray: box visits %.2f, leaf visits %.2f, exact tests %.2f" % (v[5] / v[0], v[6] / v[0], 64.0 * v[4] / v[0]))
