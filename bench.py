@@ -157,6 +157,10 @@ def valu_roofline(key, kernel, segments_per_launch, kernel_ms, spp_per_launch, f
         lane_ops = prof["valu_lane_ops_per_segment"] * seg_per_s / 1e12
         out["achieved"] = round(lane_ops, 3)
         out["frac"] = round(lane_ops / PEAK_VALU_LANE_TOPS, 4)
+        # the same split in two: share of the VALU issue slots used (one wave instruction per SIMD every
+        # two clocks), and lanes active per instruction; frac = issue_slots_used x active_lanes / 64
+        issue = prof["valu_wave_insts_per_wave_segment"] / 64.0 * seg_per_s / (1024 * 2.4e9 / 2.0)
+        out["valu_issue_slots_used"] = round(issue, 4)
         out["counters"] = {
             "valu_lane_ops_per_segment": prof["valu_lane_ops_per_segment"],
             "valu_wave_insts_per_wave_segment": prof["valu_wave_insts_per_wave_segment"],
