@@ -170,7 +170,8 @@ int rt_render(rt_ctx *ctx, const rt_params *params);
  *   segments_device uint64 the segment count is added to, or NULL
  * Limits: 2..65536 pixels per side and at most RT_STATIC_MAX_PIXELS pixels, anything
  * larger is RT_E_BADARG; the ring holds RT_STATIC_MAX_WAVES wavefronts (a 256-CU GPU
- * filled to 16 per CU), a launch is cut to that many on a larger device.  Every call
+ * filled to 16 per CU, which is all a scene with a box tree uses; rt_render gives a
+ * scene without one twice as many), a launch is cut to that many.  Every call
  * on one GPU uses that GPU's one array: calls on the same GPU that overlap in time
  * (two contexts, two host threads) race; calls on one context are ordered by its
  * stream.  Asynchronous like rt_render; sums are bit-identical to rt_render's. */
