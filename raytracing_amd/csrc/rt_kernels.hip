@@ -598,7 +598,9 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
     // per-level constants where a lane can index them by its own level
 #pragma unroll
     for (uint32_t L = 0; L < DEV_MAX_LEVELS; ++L) { tbl.base[L] = run.lo[8 + L]; tbl.count[L] = run.hi[L]; }
-    const float S = __builtin_sqrtf(len2(ray.o)) + __uint_as_float(run.hi[8]);
+    // (S only has to be an upper bound and 1/d only feeds the widened slab test: the hardware's
+    // 1-ulp square root and reciprocal do, the square root scaled up by 8 ulp)
+    const float S = __builtin_amdgcn_sqrtf(len2(ray.o)) * 1.000001f + __uint_as_float(run.hi[8]);
     float reach_pad = 0.0f;
     if (KIND == DEV_SPHERE) {
         const float kS = S * (1.0f / 524288.0f);
@@ -609,9 +611,9 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
     // 1/d clamped to +-1e19: a zero component would make plane * inv and k infinities of
     // opposite sign.  With |d| in (1e-6, 1e6) (see scan_tree) a component below 1e-19 moves
     // the ray by less than 2e-13 S over any distance that matters, far inside the pad.
-    const float ix = __builtin_fminf(__builtin_fmaxf(1.0f / ray.d.x, -1e19f), 1e19f);
-    const float iy = __builtin_fminf(__builtin_fmaxf(1.0f / ray.d.y, -1e19f), 1e19f);
-    const float iz = __builtin_fminf(__builtin_fmaxf(1.0f / ray.d.z, -1e19f), 1e19f);
+    const float ix = __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_rcpf(ray.d.x), -1e19f), 1e19f);
+    const float iy = __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_rcpf(ray.d.y), -1e19f), 1e19f);
+    const float iz = __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_rcpf(ray.d.z), -1e19f), 1e19f);
     const float klx = -((ray.o.x + pad) * ix), kly = -((ray.o.y + pad) * iy), klz = -((ray.o.z + pad) * iz);
     const float khx = -((ray.o.x - pad) * ix), khy = -((ray.o.y - pad) * iy), khz = -((ray.o.z - pad) * iz);
     const uint32_t top = run.n_levels - 1u;
