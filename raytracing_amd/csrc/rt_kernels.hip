@@ -1109,37 +1109,53 @@ void render_tiles(KernArgs by_value) {
 
     // All items of the unit in `slot` are finished and their colours stored (by lanes of
     // this wave): its pixels are added up, one pixel per lane.
-    auto finish_unit = [&](uint32_t slot) {
+    // Ring slots whose items are all finished and stored but not added up yet (bit = slot,
+    // wave-uniform).  They are added up together, as late as possible: when one of them is needed
+    // for a new unit, or at the end.  One unit alone keeps as many lanes busy as it has pixels (8 of
+    // 64 at 64 samples per launch) for as many dependent additions as the launch has samples.
+    uint32_t unsummed = 0u;
+    auto finish_units = [&](uint32_t slots) {
         const RT_CONST_AS KernArgs *k = args();
         float4 *const accum = k->fr.accum;
         const uint32_t sample_count = k->p.sample_count;
-        const uint32_t xy = ring.xy[slot];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // the unit's pixel number `lane` (see where()): column lane % 8, row lane / 8
-        const uint32_t pi = (xy & 0xffffu) + (lane & 7u), pj = (xy >> 16) + (lane >> 3);
-        if (lane < unit_px && pi < W && pj < H) {
-            const size_t pix_out = (size_t)(H - 1u - pj) * W + pi;   // src/raytracer.rs:265
-            float4 acc = accum[pix_out];
-            V3 px = mk(acc.x, acc.y, acc.z);
-            // with a depth budget of 0 every sample is black and nothing was traced
-            const uint32_t n_add = max_bounces > 0 ? sample_count : 0u;
-            // sample k of the unit's pixel `lane` is item lane + pixels of the unit * k
-            // (a wave-uniform base and a 32-bit index: the items of a ring slot number 512 at most)
-            const StagedRgb *src = stage + (slot << ITEM_BITS);
-            uint32_t k = 0;
-            // sum_batch_of(MODES) loads on the way at a time; the additions keep their order (src/raytracer.rs:262)
-            for (; k + sum_batch_of(MODES) <= n_add; k += sum_batch_of(MODES)) {
-                StagedRgb c[sum_batch_of(MODES)];
+        // the slots in ascending order
+        uint32_t rest = slots;
+        const uint32_t n_slots = (uint32_t)__builtin_popcount(slots);
+        const uint32_t s0 = (uint32_t)__builtin_ctz(rest | 16u); rest &= rest - 1u;
+        const uint32_t s1 = (uint32_t)__builtin_ctz(rest | 16u); rest &= rest - 1u;
+        const uint32_t s2 = (uint32_t)__builtin_ctz(rest | 16u); rest &= rest - 1u;
+        const uint32_t s3 = (uint32_t)__builtin_ctz(rest | 16u);
+        const uint32_t per_pass = 64u >> unit_px_log2;            // units the lanes of the wave cover at once
+        for (uint32_t first = 0; first < n_slots; first += per_pass) {
+            const uint32_t u = first + (lane >> unit_px_log2);    // this lane's unit among them,
+            const uint32_t q = lane & (unit_px - 1u);             // and its pixel of the unit (see where()): column q % 8, row q / 8
+            const uint32_t slot = u == 0u ? s0 : u == 1u ? s1 : u == 2u ? s2 : s3;
+            const uint32_t xy = ring.xy[slot & 3u];
+            const uint32_t pi = (xy & 0xffffu) + (q & 7u), pj = (xy >> 16) + (q >> 3);
+            if (u < n_slots && pi < W && pj < H) {
+                const size_t pix_out = (size_t)(H - 1u - pj) * W + pi;   // src/raytracer.rs:265
+                float4 acc = accum[pix_out];
+                V3 px = mk(acc.x, acc.y, acc.z);
+                // with a depth budget of 0 every sample is black and nothing was traced
+                const uint32_t n_add = max_bounces > 0 ? sample_count : 0u;
+                // sample n of pixel q of the unit in `slot` is item q + pixels of the unit * n of that slot
+                const uint32_t item0 = (slot << ITEM_BITS) + q;
+                uint32_t n = 0;
+                // sum_batch_of(MODES) loads on the way at a time; the additions keep their order (src/raytracer.rs:262)
+                for (; n + sum_batch_of(MODES) <= n_add; n += sum_batch_of(MODES)) {
+                    StagedRgb c[sum_batch_of(MODES)];
 #pragma unroll
-                for (uint32_t m = 0; m < sum_batch_of(MODES); ++m) c[m] = src[lane + ((k + m) << unit_px_log2)];
+                    for (uint32_t m = 0; m < sum_batch_of(MODES); ++m) c[m] = stage[item0 + ((n + m) << unit_px_log2)];
 #pragma unroll
-                for (uint32_t m = 0; m < sum_batch_of(MODES); ++m) px = px + mk(c[m].r, c[m].g, c[m].b);
+                    for (uint32_t m = 0; m < sum_batch_of(MODES); ++m) px = px + mk(c[m].r, c[m].g, c[m].b);
+                }
+                for (; n < n_add; ++n) {
+                    const StagedRgb c = stage[item0 + (n << unit_px_log2)];
+                    px = px + mk(c.r, c.g, c.b);
+                }
+                accum[pix_out] = make_float4(px.x, px.y, px.z, acc.w + (float)sample_count);
             }
-            for (; k < n_add; ++k) {
-                const StagedRgb c = src[lane + (k << unit_px_log2)];
-                px = px + mk(c.r, c.g, c.b);
-            }
-            accum[pix_out] = make_float4(px.x, px.y, px.z, acc.w + (float)sample_count);
         }
     };
 
@@ -1154,6 +1170,7 @@ void render_tiles(KernArgs by_value) {
                 if (queue_empty) break;
                 const uint32_t slot = (cur_slot + 1u) & 3u;
                 if (ring.left[slot] != 0u) break;
+                if (unsummed & (1u << slot)) { finish_units(unsummed); unsummed = 0u; }
                 const RT_CONST_AS KernArgs *k = args();
                 const uint32_t tiles_x = (W + TILE - 1u) / TILE;
                 const uint32_t sub_log2 = 6u - unit_px_log2;                  // units per tile, log2
@@ -1173,7 +1190,7 @@ void render_tiles(KernArgs by_value) {
                 if (lane == 0u) { ring.xy[slot] = x0 | (y0 << 16); ring.left[slot] = left; }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 cur_slot = slot; cur_next = 0u; cur_n = max_bounces > 0u ? sample_count << unit_px_log2 : 0u;
-                if (left == 0u) { finish_unit(slot); continue; }
+                if (left == 0u) { unsummed |= 1u << slot; continue; }
             }
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
             const uint32_t k = cur_next + rank;
@@ -1281,7 +1298,7 @@ void render_tiles(KernArgs by_value) {
             const uint32_t left = ring.left[slot] - (uint32_t)__builtin_popcountll(same);
             if (lane == 0u) ring.left[slot] = left;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (left == 0u) finish_unit(slot);
+            if (left == 0u) unsummed |= 1u << slot;
         }
 #ifdef RTK_TIMES
         const unsigned long long tm4 = __builtin_readcyclecounter();
@@ -1293,6 +1310,7 @@ void render_tiles(KernArgs by_value) {
         tm_rest += __builtin_readcyclecounter() - tm1;
 #endif
     }
+    if (unsummed != 0u) finish_units(unsummed);
 #ifdef RTK_TIMES
     // development aid: wave time inside the closest-hit scan and outside it
     if (lane == 0) {
