@@ -15,3 +15,48 @@ def test_short_sequences_give_the_bits_of_division_and_sqrt():
             assert (bad_div, bad_sqrt) == (0, 0), (seed, bad_div, bad_sqrt)
             total += 1 << 28
         assert total >= 10 ** 9
+
+
+# ---------------------------------------------------------------- the ranges around the short sequences
+def _camera(origin, scale):
+    """a pinhole camera at `origin` looking down -z whose ray directions are `scale` long"""
+    from raytracing_amd import _lib
+    cam = _lib.rt_camera()
+    cam.origin[:] = origin
+    cam.lower_left_corner[:] = (origin[0] - scale, origin[1] - 0.6 * scale, origin[2] - scale)
+    cam.horizontal[:] = (2.0 * scale, 0.0, 0.0)
+    cam.vertical[:] = (0.0, 1.2 * scale, 0.0)
+    cam.u[:] = (1.0, 0.0, 0.0)
+    cam.v[:] = (0.0, 1.0, 0.0)
+    cam.lens_radius = 0.0
+    return cam
+
+
+@pytest.mark.parametrize("scale", [2.0 ** -13, 2.0 ** -12, 2.0 ** -11, 1.0, 2.0 ** 11, 2.0 ** 12, 2.0 ** 13])
+@pytest.mark.parametrize("t_min", [2.0 ** -21, 2.0 ** -20, 1e-3])
+def test_direction_lengths_and_t_min_around_the_limits(renderer, oracle, tables, scale, t_min):
+    """|d|^2 on both sides of 2^-24 and 2^24 and t_min on both sides of 2^-20: the wave takes the short
+    sequences on one side and `/`, sqrtf on the other, and must agree with the oracle on both"""
+    import numpy as np
+    from raytracing_amd import Dielectric, HittableList, Lambertian, Metal, Plane, Sphere, make_params
+    from tests.test_gpu_parity import check
+    s = HittableList()
+    s.add(Sphere((0.0, 0.0, -3.0), 1.0, Metal((0.8, 0.7, 0.6), 0.1)))
+    s.add(Sphere((1.5, 0.2, -2.5), 0.5, Dielectric((1.0, 1.0, 1.0), 1.5)))
+    s.add(Sphere((-1.5, 0.0, -2.0), -0.4, Lambertian((0.3, 0.6, 0.3))))
+    s.add(Plane((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), Lambertian((0.5, 0.5, 0.5))))
+    check(renderer, oracle, tables, s.flatten(), _camera((0.0, 0.0, 1.0), scale),
+          [make_params(48, 32, spp=4, t_min=np.float32(t_min))])
+
+
+@pytest.mark.parametrize("far", [2.0 ** 29, 2.0 ** 30, 2.0 ** 30 * 1.001, 2.0 ** 31])
+def test_origins_and_spheres_around_the_coordinate_limit(renderer, oracle, tables, far):
+    """ray origins and sphere centres on both sides of 2^30, radii on both sides of 2^-30"""
+    import numpy as np
+    from raytracing_amd import HittableList, Lambertian, Metal, Sphere, make_params
+    from tests.test_gpu_parity import check
+    s = HittableList()
+    s.add(Sphere((far, 0.0, -far / 4), far / 8, Metal((0.8, 0.7, 0.6), 0.0)))
+    s.add(Sphere((far - far / 16, far / 32, far / 8), far / 64, Lambertian((0.3, 0.6, 0.3))))
+    s.add(Sphere((far, 0.0, far / 2), float(np.float32(2.0 ** -30) * np.float32(far / 2.0 ** 30)), Metal((0.5, 0.5, 0.5), 0.0)))
+    check(renderer, oracle, tables, s.flatten(), _camera((far, 0.0, far / 2), 1.0), [make_params(48, 32, spp=2)])
