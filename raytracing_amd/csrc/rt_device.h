@@ -38,7 +38,7 @@ struct DevRun {
                           // by the slot offsets of the n_unbounded primitives the tree does not hold
     uint32_t level_base[DEV_MAX_LEVELS];   // RUN_TREE: float4 offset of each level in tree_rec; RUN_FLAT: [0] = first step
     uint32_t level_aux[DEV_MAX_LEVELS];    // RUN_TREE: boxes at each level; RUN_FLAT: [0] = float bits of 1 - eps
-    float reach;          // RUN_TREE: max over bounded balls of |centre| + radius
+    float reach;          // RUN_TREE, RUN_FLAT: at least |centre| + |radius| of every bounded ball (|x| of every box corner)
     float inv_2rho;       // RUN_TREE of spheres: 1 / (2 * smallest |radius|), +inf when that is 0 or for triangles
     uint32_t n_unbounded; // RUN_TREE: primitives with non-finite or huge coordinates, tested for every ray
     uint32_t pad[5];

@@ -432,8 +432,9 @@ __device__ __forceinline__ void tri_exact(const SceneView &sc, uint32_t slot, in
 // The test never ACCEPTS anything: survivors run the exact test itself.
 // NaN intermediates compare false and survive.  The bounds above are relative
 // ones and need finite, normal intermediates: a ray whose |d|^2 leaves
-// (1e-12, 1e12) or whose |o|^2 reaches 1e36 (Sphere::hit then works with
-// infinities and accepts NaN roots) gets |o|^2 = NaN and rejects nothing.
+// (1e-12, 1e12) or whose |o|^2 reaches 1e36 gets |o|^2 = NaN and rejects
+// nothing, and so does one with |d|^2 (|o| + extent of the run)^2 >= 1e37 (scan_flat:
+// Sphere::hit may then work with infinities and accept NaN roots).
 // ----------------------------------------------------------------------
 struct Cull { float ux, uy, uz, nou, ax, ay, az, oo; };
 
@@ -519,7 +520,12 @@ __device__ __forceinline__ void leaf_exact(const SceneView &sc, const RunView &r
 // ----------------------------------------------------------------------
 __device__ __forceinline__ void scan_flat(const SceneView &sc, const RunView &run, const Cull &cull, bool tracing,
                                           const Ray &ray, const RayAux &aux, float t_min, Hit &h, bool &ff_shared) {
-    const float oo_keep = tracing ? cull.oo * run.level_keep(0) : __builtin_inff();
+    // Every intermediate of Sphere::hit stays below 2 a S^2, S = |o| + reach >= |o - c| + |r| for the
+    // run's bounded spheres.  Where that may overflow, the discriminant can come out as inf - inf and
+    // the reference accepts the NaN root of a sphere the ray passes far from: nothing is rejected then.
+    const float S = __builtin_amdgcn_sqrtf(cull.oo) * 1.000001f + __uint_as_float(run.hi[8]);
+    const float oo = aux.a * (S * S) < 1e37f ? cull.oo : __builtin_nanf("");
+    const float oo_keep = tracing ? oo * run.level_keep(0) : __builtin_inff();
     const RT_CONST_AS f16 *rec = sc.cull_rec + 2u * run.level_base(0);
     const uint32_t trips = run.top_steps / 2u;
     f16 a0 = rec[0], a1 = rec[1];
@@ -736,7 +742,8 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
 // distance is NaN (src/geometry/mod.rs:74: both comparisons fail and the
 // sphere is accepted, whatever is held).  Rays that enter with such numbers
 // (non-finite direction or one outside 1e-6 .. 1e6 in length, NaN closest_so_far
-// inherited from an earlier run, huge origins) are kept out of the walk; a lane whose closest_so_far
+// inherited from an earlier run, huge origins, and for spheres any |d| (|o| + extent of the run) at which
+// the discriminant could overflow) are kept out of the walk; a lane whose closest_so_far
 // turns NaN (a primitive with NaN/overflowing coordinates) drops out of it.  Both kinds then
 // take the run in list order, the second from the state it entered with.  Primitives that
 // cannot be bounded are not in the tree: the run lists them, and every ray tests them first.
@@ -747,8 +754,20 @@ __device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &ru
                                           const Ray &ray, const RayAux &aux, float t_min, Hit &h, bool &ff_shared) {
     const float big = 1e18f;
     const float a = aux.a;
-    const bool tame = a > 1e-12f && a < 1e12f && h.t == h.t &&
-                      __builtin_fabsf(ray.o.x) < big && __builtin_fabsf(ray.o.y) < big && __builtin_fabsf(ray.o.z) < big;
+    bool tame = a > 1e-12f && a < 1e12f && h.t == h.t &&
+                __builtin_fabsf(ray.o.x) < big && __builtin_fabsf(ray.o.y) < big && __builtin_fabsf(ray.o.z) < big;
+    if (KIND == DEV_SPHERE) {
+        // Every intermediate of Sphere::hit stays below 2 a S^2 (S as in walk_tree).  Where that may
+        // overflow, the discriminant can come out as inf - inf and the reference accepts the NaN root
+        // of a sphere the ray passes far from, which no box can stand for.  (The triangle test cannot
+        // accept such a distance: its gate compares the hit point with finite bounds.)
+        // At the other end, below 1e-20 its products may underflow and the relative bound on the
+        // discriminant that the pad of the boxes is made from no longer holds.  (Above it a sphere
+        // with a |o - c|^2 < 1e-36 has the origin inside its padded box and is never skipped.)
+        const float S = __builtin_amdgcn_sqrtf(len2(ray.o)) * 1.000001f + __uint_as_float(run.hi[8]);
+        const float aSS = a * (S * S);
+        tame = tame && aSS > 1e-20f && aSS < 1e37f;
+    }
     const bool walking = tracing && tame;
     bool listed = tracing && !tame;   // lanes that take the run in list order
     if (__builtin_amdgcn_ballot_w64(walking) != 0ull) {
@@ -1070,8 +1089,11 @@ void render_tiles(KernArgs by_value) {
     uint32_t cur_slot = 3u, cur_next = 0u, cur_n = 0u;
     bool queue_empty = false;
     // the queue is read one unit ahead, so that the answer is there when it is needed
-    uint32_t unit_ahead = 0u;
-    if (lane == 0u) unit_ahead = atomicAdd(args0->fr.queue, 1u);
+    // (a wave's first unit is the one with its own number: thousands of waves asking the counter
+    // in the launch's first microsecond would queue up behind one another - the counter hands out
+    // the units after those)
+    const uint32_t grid_waves = gridDim.x * (uint32_t)waves_of(MODES);
+    uint32_t unit_ahead = blockIdx.x * (uint32_t)waves_of(MODES) + wave;
 
     struct Where { uint32_t i, j, s; };      // column, row from the bottom, sample
     auto where = [&](uint32_t it) {
@@ -1178,7 +1200,7 @@ void render_tiles(KernArgs by_value) {
                 const uint32_t sample_count = k->p.sample_count;
                 const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit_ahead);
                 if (u >= n_units) { queue_empty = true; break; }
-                if (lane == 0u) unit_ahead = atomicAdd(k->fr.queue, 1u);
+                if (lane == 0u) unit_ahead = grid_waves + atomicAdd(k->fr.queue, 1u);
                 const uint32_t t = u >> sub_log2, sub = u & ((1u << sub_log2) - 1u);
                 const uint32_t by = t / tiles_x, tx = t - by * tiles_x;
                 const uint32_t band = k->p.band_begin + by * k->p.band_stride;
@@ -1489,7 +1511,7 @@ hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_
     }
     if (((uint64_t)p.sample_count << unit_px_log2) > max_items) return hipErrorInvalidValue;
     const uint64_t n_units = n_tiles << (6 - unit_px_log2);
-    if (n_units >= 0xffffffffull - resident * waves) return hipErrorInvalidValue;
+    if (n_units >= 0xffffffffull - 2u * resident * waves) return hipErrorInvalidValue;   // unit numbers handed out: below n_units + 2 x waves
     // as many workgroups as the chip holds, fewer when there are not that many work units
     const uint64_t groups = std::max<uint64_t>(1u, std::min<uint64_t>(resident, (n_units + waves - 1u) / waves));
     dim3 grid((uint32_t)groups, 1, 1), block(waves * 64, 1, 1);

@@ -343,7 +343,11 @@ int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::strin
                 build_tree(sc, run, boxes, rho_min);
             } else if (run.mode == RUN_FLAT) {
                 std::vector<float4> recs;
-                for (const Ball &b : sorted) recs.push_back(reject_record(b, LEAF_EPS_SPHERE));
+                for (const Ball &b : sorted) {
+                    recs.push_back(reject_record(b, LEAF_EPS_SPHERE));
+                    if (!unbounded(b))
+                        run.reach = std::max(run.reach, round_up(std::sqrt(b.x * b.x + b.y * b.y + b.z * b.z) + std::abs(b.r)));
+                }
                 while (recs.size() % 16) recs.push_back(NEVER_PASS);   // two steps per loop trip
                 run.level_base[0] = (uint32_t)(sc.cull_rec.size() / 8);
                 run.level_aux[0] = float_to_bits((float)(1.0 - LEAF_EPS_SPHERE));

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from raytracing_amd import Renderer, load_tables, make_params  # noqa: E402
 from tests import oracle_lib  # noqa: E402
-from tools.stress_tree_vs_list import scene  # noqa: E402
+from tools.stress_tree_vs_list import perturb, scene  # noqa: E402
 
 
 POISON = 0.05      # share of scenes that get non-finite or huge coordinates
@@ -33,32 +33,13 @@ def main():
     orc = oracle_lib.load()
     threads = min(16, os.cpu_count() or 1)
     t0 = time.time()
-    k = bad = 0
+    k = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # number of the first scene (to repeat one scene of a run)
+    bad = 0
     rays = 0
     while time.time() - t0 < budget:
         rng = np.random.default_rng(seed0 + k)
         flat, cam = scene(rng)
-        if rng.random() < POISON:
-            # a few primitives with NaN, infinite or huge coordinates (they hit every ray with a NaN
-            # distance, or none, whatever the reference's arithmetic yields)
-            a = flat.arrays
-            bad_values = np.array([np.nan, np.inf, -np.inf, 1e19, -3e25, 1e38], dtype=np.float32)
-            for key in ("sph_cx", "sph_r", "tri_v0y", "tri_v1x", "tri_v2z", "cb_cx", "pl_py"):
-                if len(a[key]) and rng.random() < 0.5:
-                    a[key][int(rng.integers(0, len(a[key])))] = bad_values[int(rng.integers(0, len(bad_values)))]
-        if rng.random() < 0.06:
-            # directions of extreme length, or an origin so far away that |o|^2 overflows: such rays
-            # bypass every conservative test and take the list as the reference does
-            c = cam.struct
-            scale = float(rng.choice([1e-25, 1e-9, 1e8, 1e20, 1.0]))
-            shift = float(rng.choice([0.0, 0.0, 1e17, 3e19, 1e30]))
-            o = np.array(c.origin[:], dtype=np.float32)
-            llc = np.array(c.lower_left_corner[:], dtype=np.float32)
-            o2 = (o + np.float32(shift)).astype(np.float32)
-            c.lower_left_corner[:] = [float(x) for x in (o2 + (llc - o) * np.float32(scale)).astype(np.float32)]
-            c.origin[:] = [float(x) for x in o2]
-            c.horizontal[:] = [float(np.float32(x) * np.float32(scale)) for x in c.horizontal[:]]
-            c.vertical[:] = [float(np.float32(x) * np.float32(scale)) for x in c.vertical[:]]
+        notes = perturb(rng, flat, cam, POISON)
         t_min = 0.001 if rng.random() < 0.8 else float(rng.choice([-1.0, 0.0, 0.05, 2.0]))
         w, h = [(96, 54), (61, 43), (130, 20), (33, 70)][int(rng.integers(0, 4))]
         stride = 1 if rng.random() < 0.7 else 3
@@ -88,8 +69,15 @@ def main():
         rays += seg
         if not same:
             bad += 1
-            print("MISMATCH seed", seed0 + k, "t_min", t_min, "sums", int((a != b)[~nan].sum()),
+            print("MISMATCH seed", seed0 + k, "scene number", k, "t_min", t_min, "sums", int((a != b)[~nan].sum()),
                   "ids", int((ids != o_ids).sum()), "segments", seg, o_seg, flush=True)
+            if os.environ.get("RT_FUZZ_VERBOSE"):
+                d = (a != b) & ~nan
+                ys, xs, cs = np.nonzero(d)
+                print(" size", p.width, p.height, "spp", p.spp, "bounces", p.max_bounces, "bands", p.band_begin, p.band_stride,
+                      "counts", flat.counts, "calls", len(calls), "perturbed:", notes)
+                for y, x, c in list(zip(ys, xs, cs))[:12]:
+                    print("  pixel", x, y, "channel", c, "gpu", acc[y, x, c], "oracle", o_acc[y, x, c], "id", ids[y, x])
         k += 1
         if k % 20 == 0:
             print("scenes", k, "segments %.3g" % rays, "mismatches", bad, "t %.0f s" % (time.time() - t0), flush=True)

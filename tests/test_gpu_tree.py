@@ -307,6 +307,35 @@ def test_far_away_camera_and_scene(renderer, oracle, tables):
     check(renderer, oracle, tables, s.flatten(), cam, [make_params(96, 64, spp=3)])
 
 
+def _camera_looking_at_world_origin(origin, scale):
+    """pinhole camera at `origin` whose ray directions are about `scale` long"""
+    o = np.array(origin, dtype=np.float64)
+    w = -o / np.linalg.norm(o)
+    u = np.cross((0.0, 1.0, 0.0), w) if abs(w[1]) < 0.9 else np.cross((1.0, 0.0, 0.0), w)
+    u /= np.linalg.norm(u)
+    v = np.cross(w, u)
+    cam = _lib.rt_camera()
+    cam.origin[:] = tuple(o)
+    hor, ver = 0.6 * scale * u, 0.4 * scale * v
+    cam.lower_left_corner[:] = tuple(o - hor / 2 - ver / 2 + scale * w)
+    cam.horizontal[:] = tuple(hor)
+    cam.vertical[:] = tuple(ver)
+    cam.u[:] = tuple(u)
+    cam.v[:] = tuple(v)
+    cam.lens_radius = 0.0
+    return cam
+
+
+def _tree_and_flat_scan_against_oracle(renderer, oracle, tables, flat, cam, p):
+    orc = render_oracle(oracle, tables, flat, cam, p)
+    _same_with_nans(render_gpu(renderer, flat, cam, p), orc, oracle)
+    os.environ["RT_HIP_FLAT_SCAN"] = "1"
+    try:
+        _same_with_nans(render_gpu(renderer, flat, cam, p), orc, oracle)
+    finally:
+        del os.environ["RT_HIP_FLAT_SCAN"]
+
+
 @pytest.mark.parametrize("n_spheres", [40, 200])
 def test_rays_with_extreme_origins_and_directions(renderer, oracle, tables, n_spheres):
     """origins from 1e17 to 1e30 (|o|^2 overflows f32 from 1.8e19 on) and directions of length 1e-25
@@ -323,27 +352,40 @@ def test_rays_with_extreme_origins_and_directions(renderer, oracle, tables, n_sp
              ((0.0, 1e30, 0.0), 1.0), ((0.0, 0.0, 8.0), 1e7), ((0.0, 0.0, 8.0), 1e20), ((0.0, 0.0, 8.0), 1e-8),
              ((0.0, 0.0, 8.0), 1e-25), ((1e10, 0.0, 1e10), 1e15)]
     for origin, scale in cases:
-        o = np.array(origin, dtype=np.float64)
-        w = -o / np.linalg.norm(o)                        # looks at the world origin
-        u = np.cross((0.0, 1.0, 0.0), w) if abs(w[1]) < 0.9 else np.cross((1.0, 0.0, 0.0), w)
-        u /= np.linalg.norm(u)
-        v = np.cross(w, u)
-        cam = _lib.rt_camera()
-        cam.origin[:] = tuple(o)
-        hor, ver = 0.6 * scale * u, 0.4 * scale * v
-        cam.lower_left_corner[:] = tuple(o - hor / 2 - ver / 2 + scale * w)
-        cam.horizontal[:] = tuple(hor)
-        cam.vertical[:] = tuple(ver)
-        cam.u[:] = tuple(u)
-        cam.v[:] = tuple(v)
-        cam.lens_radius = 0.0
-        orc = render_oracle(oracle, tables, flat, cam, p)
-        _same_with_nans(render_gpu(renderer, flat, cam, p), orc, oracle)
-        os.environ["RT_HIP_FLAT_SCAN"] = "1"
-        try:
-            _same_with_nans(render_gpu(renderer, flat, cam, p), orc, oracle)
-        finally:
-            del os.environ["RT_HIP_FLAT_SCAN"]
+        _tree_and_flat_scan_against_oracle(renderer, oracle, tables, flat,
+                                           _camera_looking_at_world_origin(origin, scale), p)
+
+
+@pytest.mark.parametrize("n_spheres", [40, 200])
+@pytest.mark.parametrize("far,length", [(8e17, 1.0), (8e17, 3.0), (8e17, 5.0), (8e17, 30.0), (1e14, 3e5), (1e16, 1000.0),
+                                        (1e16, 3000.0), (3e12, 9e5), (3e13, 9e5), (2e10, 9.9e5)])
+def test_rays_whose_discriminant_overflows_for_ordinary_spheres(renderer, oracle, tables, n_spheres, far, length):
+    """origins and direction lengths that each stay in the ordinary range but whose product does
+    not: half_b^2 and a*c (src/geometry/mod.rs:63-66) pass 3.4e38 from |d| |o - c| = 1.8e19 on, the
+    discriminant is inf - inf and every such sphere is accepted with a NaN root, also spheres the
+    ray passes far from.  A camera cannot make such rays (its directions are differences of
+    points near the origin); rays scattered by a plane at height `far` whose normal is `length`
+    long can (Plane::hit does not normalise, src/geometry/mod.rs:112-130).  Products on both
+    sides of the limit, in the rejection scan (40 spheres) and in the tree (200)."""
+    rng = np.random.default_rng(15)
+    s = HittableList()
+    for _ in range(n_spheres):
+        s.add(Sphere(tuple(rng.uniform(-30, 30, 3) + np.array((0.0, -60.0, 0.0))), float(rng.uniform(0.2, 3.0)), _mat(rng)))
+    s.add(Plane((0.0, length, 0.0), (0.0, far, 0.0), Lambertian((0.8, 0.6, 0.4)) if n_spheres == 40 else Metal((0.8, 0.6, 0.4), 0.3)))
+    cam = _cam((0.0, 0.0, 0.0), look_at=(0.1, 1.0, 0.2), fov=50.0)
+    _tree_and_flat_scan_against_oracle(renderer, oracle, tables, s.flatten(), cam, [make_params(40, 24, spp=2, max_bounces=4)])
+
+
+def test_bounce_from_a_far_plane_back_towards_a_sphere_run(renderer, oracle, tables):
+    """a plane at 1e19 is hit at t = 1e18; the scattered rays start there with directions of length
+    ten and more, and the discriminants of all spheres of the run overflow (found by the fuzzer)"""
+    rng = np.random.default_rng(16)
+    s = HittableList()
+    for _ in range(300):
+        s.add(Sphere(tuple(np.array((470.0, 2260.0, 1790.0)) + rng.uniform(-60, 60, 3)), float(rng.uniform(0.3, 7.0)), _mat(rng)))
+    s.add(Plane((11.2, 2.0, 14.2), (500.0, 1e19, 1800.0), Lambertian((0.88, 0.40, 0.29))))
+    cam = _cam((465.0, 2311.0, 1745.0), look_at=(470.0, 2260.0, 1790.0), fov=80.0)
+    _tree_and_flat_scan_against_oracle(renderer, oracle, tables, s.flatten(), cam, [make_params(96, 48, spp=3, max_bounces=4)])
 
 
 def test_list_order_scan_equals_tree_on_the_gpu(renderer):

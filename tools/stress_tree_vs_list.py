@@ -1,7 +1,8 @@
 """Fuzz: the tree scan against the list-order scan of the same library on the GPU
 (RT_HIP_FLAT_SCAN=1 disables the tree; triangles then run their exact test one by one
 and spheres the rejection scan), over random scenes at frame sizes far beyond the CPU
-oracle.  Every output must be bit-identical.  usage: stress_tree_vs_list.py [seconds] [seed0]"""
+oracle.  Every output must be bit-identical.
+usage: stress_tree_vs_list.py [seconds] [seed0] [share of scenes with NaN/inf/huge/tiny numbers, default 0]"""
 import os
 import sys
 import time
@@ -78,9 +79,61 @@ def scene(rng):
     return flat, cam
 
 
+BAD_VALUES = np.array([np.nan, np.inf, -np.inf, 1e19, -3e25, 1e38, 1e14, -1e16, 8e17, 9e14, -1.1e15], dtype=np.float32)
+COORDINATES = (["sph_cx", "sph_cy", "sph_cz", "sph_r", "cb_cx", "cb_cy", "cb_cz", "cb_w", "cb_h", "cb_d",
+                "pl_px", "pl_py", "pl_pz"] + ["tri_" + v + c for v in ("v0", "v1", "v2") for c in "xyz"])
+
+
+def perturb(rng, flat, cam, share):
+    """With probability `share`: numbers at which the reference's f32 arithmetic leaves the ordinary
+    range.  Single coordinates that are NaN, infinite or huge (such primitives hit every ray with a
+    NaN distance, or none; a plane far away sends scattered rays back from there), plane normals
+    far from unit length (Plane::hit does not normalise, so scattered directions get that length),
+    the whole scene and camera scaled by a power of ten, and - on its own 6 % - a camera whose ray
+    directions are extremely long or short or whose origin is so far away that |o|^2 overflows.
+    Returns a list of what was done."""
+    notes = []
+    a = flat.arrays
+    if rng.random() < share:
+        for key in ("sph_cx", "sph_r", "tri_v0y", "tri_v1x", "tri_v2z", "cb_cx", "pl_py"):
+            if len(a[key]) and rng.random() < 0.5:
+                at = int(rng.integers(0, len(a[key])))
+                a[key][at] = BAD_VALUES[int(rng.integers(0, len(BAD_VALUES)))]
+                notes.append((key, at, float(a[key][at])))
+        if len(a["pl_nx"]) and rng.random() < 0.4:
+            f = np.float32(rng.choice([1e-6, 1e-3, 30.0, 3e3, 3e5]))
+            for key in ("pl_nx", "pl_ny", "pl_nz"):
+                a[key] *= f
+            notes.append(("plane normals times", float(f)))
+        if rng.random() < 0.2:
+            f = np.float32(rng.choice([1e-22, 1e-17, 1e-12, 1e-6, 1e6, 1e10, 1e13]))
+            for key in COORDINATES:
+                a[key] *= f
+            c = cam.struct
+            for field in ("origin", "lower_left_corner", "horizontal", "vertical"):
+                v = getattr(c, field)
+                v[:] = [float(np.float32(x) * f) for x in v[:]]
+            c.lens_radius = float(np.float32(c.lens_radius) * f)
+            notes.append(("everything times", float(f)))
+    if rng.random() < 0.06:
+        c = cam.struct
+        scale = float(rng.choice([1e-25, 1e-9, 1e8, 1e20, 1.0]))
+        shift = float(rng.choice([0.0, 0.0, 1e17, 3e19, 1e30]))
+        o = np.array(c.origin[:], dtype=np.float32)
+        llc = np.array(c.lower_left_corner[:], dtype=np.float32)
+        o2 = (o + np.float32(shift)).astype(np.float32)
+        c.lower_left_corner[:] = [float(x) for x in (o2 + (llc - o) * np.float32(scale)).astype(np.float32)]
+        c.origin[:] = [float(x) for x in o2]
+        c.horizontal[:] = [float(np.float32(x) * np.float32(scale)) for x in c.horizontal[:]]
+        c.vertical[:] = [float(np.float32(x) * np.float32(scale)) for x in c.vertical[:]]
+        notes.append(("camera directions times", scale, "origin plus", shift))
+    return notes
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    share = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
     r = Renderer(0, load_tables())
     t0 = time.time()
     k = 0
@@ -89,6 +142,7 @@ def main():
     while time.time() - t0 < budget:
         rng = np.random.default_rng(seed0 + k)
         flat, cam = scene(rng)
+        notes = perturb(rng, flat, cam, share) if share > 0.0 else []
         p = make_params(1280, 720, spp=2, seed=k)
         out = []
         for mode in ("tree", "list"):
@@ -102,13 +156,14 @@ def main():
             r.begin_frame(p.width, p.height)
             r.render(p)
             out.append((r.read_accum().view(np.uint32), r.read_primary_ids(), r.ray_count()))
-        same = np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+        nan = np.isnan(out[0][0].view(np.float32)) & np.isnan(out[1][0].view(np.float32))     # NaN payloads may differ
+        differ = (out[0][0] != out[1][0]) & ~nan
+        same = not differ.any() and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
         rays += out[0][2]
         if not same:
             bad += 1
-            d = (out[0][0] != out[1][0]).any(-1)
-            print("MISMATCH seed", seed0 + k, "pixels", int(d.sum()), "ids", int((out[0][1] != out[1][1]).sum()),
-                  "segments", out[0][2], out[1][2], flush=True)
+            print("MISMATCH seed", seed0 + k, "pixels", int(differ.any(-1).sum()), "ids", int((out[0][1] != out[1][1]).sum()),
+                  "segments", out[0][2], out[1][2], "perturbed:", notes, flush=True)
         k += 1
         if k % 10 == 0:
             print("scenes", k, "segments %.3g" % rays, "mismatches", bad, "t %.0f s" % (time.time() - t0), flush=True)
