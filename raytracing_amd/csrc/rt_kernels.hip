@@ -1200,7 +1200,10 @@ void render_tiles(KernArgs by_value) {
                 const uint32_t sample_count = k->p.sample_count;
                 const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit_ahead);
                 if (u >= n_units) { queue_empty = true; break; }
-                if (lane == 0u) unit_ahead = grid_waves + atomicAdd(k->fr.queue, 1u);
+                // (a launch with no more units than waves never asks the counter: thousands of
+                // requests for nothing take 30 us to answer)
+                if (grid_waves >= n_units) unit_ahead = n_units;
+                else if (lane == 0u) unit_ahead = grid_waves + atomicAdd(k->fr.queue, 1u);
                 const uint32_t t = u >> sub_log2, sub = u & ((1u << sub_log2) - 1u);
                 const uint32_t by = t / tiles_x, tx = t - by * tiles_x;
                 const uint32_t band = k->p.band_begin + by * k->p.band_stride;

@@ -57,6 +57,15 @@ V = {
  "alt cmp/mul": ["v_cmp_gt_f32_e32 vcc, {a}, {d}", "v_mul_f32_e32 {d}, {a}, {b}"] * 4,
  "alt fma/fma(sgpr)": ["v_fma_f32 {d}, {a}, {b}, {b}", "v_fma_f32 {d}, {s}, {b}, {b}"] * 4,
  "alt mul/add": ["v_mul_f32_e32 {d}, {a}, {b}", "v_add_f32_e32 {d}, {a}, {b}"] * 4,
+ "s_add only": ["s_add_u32 s24, s25, 1"] * 8,
+ "s_and_b64 only": ["s_and_b64 s[26:27], s[28:29], exec"] * 8,
+ "alt mul/s_add": ["v_mul_f32_e32 {d}, {a}, {b}", "s_add_u32 s24, s25, 1"] * 4,
+ "alt fma/s_add": ["v_fma_f32 {d}, {a}, {b}, {b}", "s_add_u32 s24, s25, 1"] * 4,
+ "alt fma/s_and_b64": ["v_fma_f32 {d}, {a}, {b}, {b}", "s_and_b64 s[26:27], s[28:29], exec"] * 4,
+ "fma, 3 s_add": ["v_fma_f32 {d}, {a}, {b}, {b}", "s_add_u32 s24, s25, 1", "s_add_u32 s24, s25, 2", "s_add_u32 s24, s25, 3"] * 2,
+ "mul, mul, s_add, s_add": ["v_mul_f32_e32 {d}, {a}, {b}", "v_mul_f32_e32 {d}, {a}, {b}", "s_add_u32 s24, s25, 1", "s_add_u32 s24, s25, 2"] * 2,
+ "s_nop 0 only": ["s_nop 0"] * 8,
+ "alt fma/s_nop 0": ["v_fma_f32 {d}, {a}, {b}, {b}", "s_nop 0"] * 4,
  "mul dependent chain (1 reg)": ["v_mul_f32_e32 {d0}, {d0}, {b}"] * 8,
  "fma dependent chain (1 reg)": ["v_fma_f32 {d0}, {d0}, {b}, {b}"] * 8,
 }
@@ -75,7 +84,7 @@ for vi, name in enumerate(names):
                                   s="s20", sp="s[20:21]"))
     body = "\\n ".join(lines)
     # destinations are 64-bit pairs; plain f32 ops write the low half
-    out.append('    if (V == %d) asm volatile("%s" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "v"(ap), "v"(bp) : "vcc", "s20", "s21", "s22", "s23");' % (vi, body))
+    out.append('    if (V == %d) asm volatile("%s" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "v"(ap), "v"(bp) : "vcc", "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29");' % (vi, body))
 out += ['  }', '  out[blockIdx.x * 256 + threadIdx.x] = r0.x + r1.x + r2.x + r3.x + r4.y + r5.x + r6.x + r7.x + q0 + q1 + q2 + q3 + q4 + q5 + q6 + q7;', '}',
         'template <int V> void run(const char *name, float *out) {',
         '  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); const int iters = 10000;',
