@@ -283,7 +283,9 @@ struct Hit {
     int kind;       // -1 = nothing hit
     uint32_t slot;  // position in the kind's device array
     int32_t id;     // position in the reference's list
-    bool ff;        // front_face as the shared temp record held it at accept time
+    uint32_t ff;    // front_face (1 or 0) as the shared temp record held it at accept time; kept as a number:
+                    // a bool carried across divergent branches lives in scalar mask registers, three scalar
+                    // instructions per join
 };
 
 // ----------------------------------------------------------------------
@@ -308,14 +310,13 @@ struct Hit {
 // t_min, so its bits are never looked at.)
 struct RayAux { float a, inv_a; bool cheap; };
 // Sphere::hit, src/geometry/mod.rs:60-94, up to the decision: true, with the hit distance in
-// `root`, when the sphere in `slot` replaces a holder at distance `closest`.  this_pos() and
+// `root`, when the sphere g replaces a holder at distance `closest`.  this_pos() and
 // holder_pos() give the list positions of the two, asked for only when the distances tie.
 template <class ThisPos, class HolderPos>
-__device__ __forceinline__ bool sphere_closer(const SceneView &sc, uint32_t slot, const Ray &ray, const RayAux &aux,
+__device__ __forceinline__ bool sphere_closer(const f4 g, const Ray &ray, const RayAux &aux,
                                               float t_min, float closest, ThisPos this_pos, HolderPos holder_pos,
                                               float &root) {
-    const float a = aux.a;
-    const f4 g = sc.sph_geom[slot];   // cx, cy, cz, radius
+    const float a = aux.a;            // g: cx, cy, cz, radius
     V3 oc = ray.o - mk(g.x, g.y, g.z);
     float half_b = dot(oc, ray.d);
     float c = len2(oc) - g.w * g.w;
@@ -345,13 +346,17 @@ __device__ __forceinline__ bool sphere_front_face(const SceneView &sc, uint32_t 
     V3 outward = div3(p - mk(g.x, g.y, g.z), g.w, cheap);
     return dot(ray.d, outward) < 0.0f;
 }
-// one sphere of a list-order scan
-__device__ __forceinline__ void sphere_exact(const SceneView &sc, uint32_t slot, int32_t id, const Ray &ray,
-                                             const RayAux &aux, float t_min, Hit &h, bool &ff_shared) {
+// one sphere of a list-order scan (g: its record, sc.sph_geom[slot])
+__device__ __forceinline__ void sphere_exact(const SceneView &sc, const f4 g, uint32_t slot, int32_t id, const Ray &ray,
+                                             const RayAux &aux, float t_min, Hit &h, uint32_t &ff_shared) {
     float root;
-    if (!sphere_closer(sc, slot, ray, aux, t_min, h.t, [&]() { return id; }, [&]() { return h.id; }, root)) return;
+    if (!sphere_closer(g, ray, aux, t_min, h.t, [&]() { return id; }, [&]() { return h.id; }, root)) return;
     h.t = root; h.kind = DEV_SPHERE; h.slot = slot; h.id = id;
-    if (sc.need_ff_shared) ff_shared = sphere_front_face(sc, slot, ray, root, aux.cheap);
+    if (sc.need_ff_shared) ff_shared = sphere_front_face(sc, slot, ray, root, aux.cheap) ? 1u : 0u;
+}
+__device__ __forceinline__ void sphere_exact(const SceneView &sc, uint32_t slot, int32_t id, const Ray &ray,
+                                             const RayAux &aux, float t_min, Hit &h, uint32_t &ff_shared) {
+    sphere_exact(sc, sc.sph_geom[slot], slot, id, ray, aux, t_min, h, ff_shared);
 }
 // same selections as `m = a > b ? a : b; m > c ? m : c` (and < for min): with a NaN operand the
 // results may differ from a fused max3, so they are spelled out
@@ -407,11 +412,11 @@ __device__ __forceinline__ bool tri_front_face(const SceneView &sc, uint32_t slo
 }
 // one triangle of a list-order scan
 __device__ __forceinline__ void tri_exact(const SceneView &sc, uint32_t slot, int32_t id, const Ray &ray,
-                                          float t_min, Hit &h, bool &ff_shared) {
+                                          float t_min, Hit &h, uint32_t &ff_shared) {
     float t;
     if (!tri_closer(sc, slot, ray, t_min, h.t, [&]() { return id; }, [&]() { return h.id; }, t)) return;
     h.t = t; h.kind = DEV_TRI; h.slot = slot; h.id = id;
-    if (sc.need_ff_shared) ff_shared = tri_front_face(sc, slot, ray);
+    if (sc.need_ff_shared) ff_shared = tri_front_face(sc, slot, ray) ? 1u : 0u;
 }
 
 // ----------------------------------------------------------------------
@@ -492,7 +497,7 @@ __device__ __forceinline__ uint32_t cull_step(const Cull &cull, float oo_keep, c
 template <int KIND>
 __device__ __forceinline__ void leaf_exact(const SceneView &sc, const RunView &run, uint32_t first_in_run,
                                            uint32_t any_bits, uint32_t lane_bits, bool list_order,
-                                           const Ray &ray, const RayAux &aux, float t_min, Hit &h, bool &ff_shared) {
+                                           const Ray &ray, const RayAux &aux, float t_min, Hit &h, uint32_t &ff_shared) {
     if (first_in_run >= run.count) return;          // a step of padding only
     const uint32_t left = run.count - first_in_run;
 #pragma unroll 1
@@ -519,7 +524,7 @@ __device__ __forceinline__ void leaf_exact(const SceneView &sc, const RunView &r
 // a whole step to arrive.
 // ----------------------------------------------------------------------
 __device__ __forceinline__ void scan_flat(const SceneView &sc, const RunView &run, const Cull &cull, bool tracing,
-                                          const Ray &ray, const RayAux &aux, float t_min, Hit &h, bool &ff_shared) {
+                                          const Ray &ray, const RayAux &aux, float t_min, Hit &h, uint32_t &ff_shared) {
     // Every intermediate of Sphere::hit stays below 2 a S^2, S = |o| + reach >= |o - c| + |r| for the
     // run's bounded spheres.  Where that may overflow, the discriminant can come out as inf - inf and
     // the reference accepts the NaN root of a sphere the ray passes far from: nothing is rejected then.
@@ -592,7 +597,7 @@ __device__ __forceinline__ bool walk_test(const SceneView &sc, uint32_t slot, co
     const RT_CONST_AS uint32_t *by_slot = KIND == DEV_SPHERE ? sc.sph_id : sc.tri_id;
     auto this_pos = [&]() { return (int32_t)by_slot[slot]; };
     auto holder_pos = [&]() { return best_slot == NO_SLOT ? entry_pos : (int32_t)by_slot[best_slot]; };
-    if (KIND == DEV_SPHERE) return sphere_closer(sc, slot, ray, aux, t_min, best_t, this_pos, holder_pos, t);
+    if (KIND == DEV_SPHERE) return sphere_closer(sc.sph_geom[slot], ray, aux, t_min, best_t, this_pos, holder_pos, t);
     return tri_closer(sc, slot, ray, t_min, best_t, this_pos, holder_pos, t);
 }
 
@@ -751,7 +756,7 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
 template <int KIND>
 __device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &run, bool tracing,
                                           TreeTable &tbl, const f4 *tree_top, uint32_t lds_from_level,
-                                          const Ray &ray, const RayAux &aux, float t_min, Hit &h, bool &ff_shared) {
+                                          const Ray &ray, const RayAux &aux, float t_min, Hit &h, uint32_t &ff_shared) {
     const float big = 1e18f;
     const float a = aux.a;
     bool tame = a > 1e-12f && a < 1e12f && h.t == h.t &&
@@ -795,8 +800,8 @@ __device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &ru
             h.id = (int32_t)(KIND == DEV_SPHERE ? sc.sph_id[best_slot] : sc.tri_id[best_slot]);
             // temp_hr.front_face as the last accepted primitive of the run left it: the run's closest
             if (sc.need_ff_shared)
-                ff_shared = KIND == DEV_SPHERE ? sphere_front_face(sc, best_slot, ray, best_t, aux.cheap)
-                                               : tri_front_face(sc, best_slot, ray);
+                ff_shared = (KIND == DEV_SPHERE ? sphere_front_face(sc, best_slot, ray, best_t, aux.cheap)
+                                                : tri_front_face(sc, best_slot, ray)) ? 1u : 0u;
         }
     }
     if (__builtin_amdgcn_ballot_w64(listed) != 0ull) {
@@ -823,8 +828,8 @@ __device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, c
     h.kind = -1;
     h.slot = 0;
     h.id = -1;
-    h.ff = true;
-    bool ff_shared = true;   // temp_hr.front_face, default true (src/geometry/mod.rs:36-39,241)
+    h.ff = 1u;
+    uint32_t ff_shared = 1u;   // temp_hr.front_face, default true (src/geometry/mod.rs:36-39,241)
     const float a = aux.a;
     Cull cull;
     bool have_cull = false;
@@ -844,7 +849,16 @@ __device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, c
                 scan_tree<DEV_TRI>(sc, run, tracing, tbl, tree_top, from, ray, aux, t_min, h, ff_shared);
             }
         } else if (run.kind == DEV_SPHERE) {
-            for (uint32_t k = 0; k < run.count; ++k)
+            // two per trip, both records requested before the first is used: the loop's own scalar
+            // instructions (13 beside 20 vector ones for a sphere that is missed, at a quarter of the
+            // rate) and the wait for the record are shared
+            uint32_t k = 0;
+            for (; k + 2u <= run.count; k += 2u) {
+                const f4 g0 = sc.sph_geom[run.first + k], g1 = sc.sph_geom[run.first + k + 1u];
+                sphere_exact(sc, g0, run.first + k, (int32_t)(run.id0 + k), ray, aux, t_min, h, ff_shared);
+                sphere_exact(sc, g1, run.first + k + 1u, (int32_t)(run.id0 + k + 1u), ray, aux, t_min, h, ff_shared);
+            }
+            if (k < run.count)
                 sphere_exact(sc, run.first + k, (int32_t)(run.id0 + k), ray, aux, t_min, h, ff_shared);
         } else if (run.kind == DEV_PLANE) {
             // Plane::hit, src/geometry/mod.rs:112-130
@@ -855,7 +869,7 @@ __device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, c
                 float t = dot(mk(p4.x, p4.y, p4.z) - ray.o, n) / dot(n, ray.d);
                 if (t < t_min || t > h.t) continue;
                 h.t = t; h.kind = DEV_PLANE; h.slot = run.first + k; h.id = (int32_t)(run.id0 + k);
-                if (sc.need_ff_shared) ff_shared = dot(ray.d, n) < 0.0f;
+                if (sc.need_ff_shared) ff_shared = dot(ray.d, n) < 0.0f ? 1u : 0u;
             }
         } else if (run.kind == DEV_CUBE) {
             // Cube::hit, src/geometry/mod.rs:158-223
@@ -895,7 +909,7 @@ __device__ __forceinline__ uint32_t shade_hit(const SceneView &sc, const float *
                                               uint32_t bounce) {
     V3 p = ray.o + ray.d * h.t;   // Ray::at, src/ray/mod.rs:19-21
     V3 normal;
-    bool ff = h.ff;
+    bool ff = h.ff != 0u;
     uint32_t mat;
     if (h.kind == DEV_SPHERE) {
         // src/geometry/mod.rs:81-86
