@@ -201,6 +201,18 @@ __host__ __device__ constexpr int waves_of(int modes) { return (modes & 2) ? RTK
 #define RTK_OCC0 8           // scenes without long runs: 64 VGPRs, no spills.  Default scene at 1080p, 64 samples:
 #endif                       // 6.40 ms with four waves per SIMD, 5.70 with five, 5.48 with six and with eight
 __host__ __device__ constexpr int occ_of(int modes) { return modes == 0 ? RTK_OCC0 : RTK_OCC; }
+// idle lanes a wave waits for before it counts finished items and hands out new ones
+// (64-sample launches of the whole frame, 1 / 16 / 24 / 32 lanes: default scene 1080p 4.97 / 4.70 / 4.57 /
+// 4.58 ms; with a tree 8 / 16 / 20 / 24 / 32 lanes: 10,000 spheres 4K 107.8 / 105.6 / 105.6 / 106.4 /
+// 107.6 ms, a million triangles 53.9 / 51.4 / 50.5 / 50.3 / 50.3, 960-triangle mesh 10.35 / 10.08 / 9.97 /
+// 9.94 / 9.97)
+#ifndef RTK_FETCH_MIN0
+#define RTK_FETCH_MIN0 24
+#endif
+#ifndef RTK_FETCH_MIN
+#define RTK_FETCH_MIN 20
+#endif
+__host__ __device__ constexpr uint32_t fetch_min_of(int modes) { return modes == 0 ? RTK_FETCH_MIN0 : RTK_FETCH_MIN; }
 constexpr int TILE = 8;   // 8x8 pixels per wavefront
 
 struct TreeTable {
@@ -904,8 +916,10 @@ __device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, c
 // Rebuild the HitRecord of the closest hit (p, normal, front_face) exactly as
 // the primitive's hit() filled it, then run its material's scatter.
 // Returns the material index; ray is replaced by the scattered ray.
+// (path_key() is asked for only where a Dielectric draws its coin)
+template <class PathKey>
 __device__ __forceinline__ uint32_t shade_hit(const SceneView &sc, const float *tbl_sphere, Ray &ray, V3 ud, const Hit &h,
-                                              bool cheap, float sp_bn, uint32_t &path_counter, uint32_t path_key,
+                                              bool cheap, float sp_bn, uint32_t &path_counter, PathKey path_key,
                                               uint32_t bounce) {
     V3 p = ray.o + ray.d * h.t;   // Ray::at, src/ray/mod.rs:19-21
     V3 normal;
@@ -976,7 +990,7 @@ __device__ __forceinline__ uint32_t shade_hit(const SceneView &sc, const float *
             // material); coin: hash of (path, bounce)
             float r0 = ff ? mb.z : mb.w;
             float refl_p = r0 + (1.0f - r0) * powi5(1.0f - cos_theta);
-            uint32_t rb = mix32(path_key + GOLDEN32 * (bounce + 1u));
+            uint32_t rb = mix32(path_key() + GOLDEN32 * (bounce + 1u));
             float coin = (float)(rb >> 8) * (1.0f / 16777216.0f);
             refl = refl_p > coin;
         }
@@ -1098,6 +1112,7 @@ void render_tiles(KernArgs by_value) {
     Ray ray;
     ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1);
     uint32_t depth_left = max_bounces, path_counter = 0;
+    float sp_bn = 0.0f;
     uint32_t n_seg = 0;
     // wave-uniform: the unit items are being handed out from
     uint32_t cur_slot = 3u, cur_next = 0u, cur_n = 0u;
@@ -1140,6 +1155,8 @@ void render_tiles(KernArgs by_value) {
         else { u = ((float)w.i + ox) / w1; v = ((float)w.j + oy) / h1; }
         ray = get_ray(k->cam, u, v, la, lb);
         path_counter = path_key_at(w, k->p.seed);
+        // BlueNoise::get_screenspace, src/denoising/mod.rs:19-23: fixed per pixel, kept for the path
+        sp_bn = k->fr.tbl_screen[128u * (w.i % 128u) + (w.j % 128u)];
         depth_left = max_bounces;
     };
 
@@ -1245,6 +1262,7 @@ void render_tiles(KernArgs by_value) {
     unsigned long long tm_scan = 0, tm_rest = 0, tm_done = 0, tm_fetch = 0, tm_fin = 0;
 #endif
     fetch(true);
+    bool parked = false;   // the lane's path is over, its colour not worked out and its item not counted yet
 
     while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
         Hit h;
@@ -1275,50 +1293,36 @@ void render_tiles(KernArgs by_value) {
             // (the arguments the shading needs are read after the scan, not kept across it)
             const RT_CONST_AS KernArgs *ks = args();
             const SceneView sc = view_of(ks->dsc, ks->fr.segments);
-            const Where at = where(item);
             const uint32_t n_stack = max_bounces - depth_left;   // hits of this path so far
-            const size_t pix_out = (size_t)(H - 1u - at.j) * W + at.i;   // src/raytracer.rs:265
-            // BlueNoise::get_screenspace, src/denoising/mod.rs:19-23: fixed per pixel
-            const float sp_bn = ks->fr.tbl_screen[128u * (at.i % 128u) + (at.j % 128u)];
-            if (at.s == 0u && n_stack == 0u) ks->fr.primary_ids[pix_out] = h.id;
+            if (n_stack == 0u) {
+                const Where at = where(item);
+                if (at.s == 0u) ks->fr.primary_ids[(size_t)(H - 1u - at.j) * W + at.i] = h.id;   // src/raytracer.rs:265
+            }
             // unit_vector(direction): the sky (src/raytracer.rs:82), Metal and Dielectric all start
             // from it; computed once for the wave instead of once per branch
             // (cheap: 2^-12 <= |d| <= 2^12, every component at most that)
             const V3 ud = div3(ray.d, aux.cheap ? sqrt_refined(aux.a) : __builtin_sqrtf(aux.a), aux.cheap);
-            V3 c;
             uint32_t n_hits = n_stack;
             if (h.kind >= 0) {
-                uint32_t mat = shade_hit(sc, lds.sphere, ray, ud, h, aux.cheap, sp_bn, path_counter, path_key_at(at, ks->p.seed), n_stack);
+                uint32_t mat = shade_hit(sc, lds.sphere, ray, ud, h, aux.cheap, sp_bn, path_counter,
+                                         [&]() { return path_key_at(where(item), ks->p.seed); }, n_stack);
                 lds.mat_stack[wave][n_stack][lane] = mat;
                 n_hits = n_stack + 1u;
                 depth_left -= 1;
                 done = depth_left == 0u;   // `if ray_bounces <= 0 { return 0 }`, src/raytracer.rs:69
-                c = mk(0.0f, 0.0f, 0.0f);
             } else {
-                c = sky(ud, ks->p.gamma != 0u);
                 done = true;
             }
 #ifdef RTK_TIMES
             const unsigned long long tm2 = __builtin_readcyclecounter();
 #endif
             if (done) {
-                // attenuation * ray_colour(...), innermost product first (src/raytracer.rs:79)
-                // (four entries per round: their fetches overlap, the products keep their order)
-                uint32_t k = n_hits;
-                while (k != 0u) {
-                    const uint32_t m0 = lds.mat_stack[wave][k - 1u][lane];
-                    const uint32_t m1 = lds.mat_stack[wave][k >= 2u ? k - 2u : 0u][lane];
-                    const uint32_t m2 = lds.mat_stack[wave][k >= 3u ? k - 3u : 0u][lane];
-                    const uint32_t m3 = lds.mat_stack[wave][k >= 4u ? k - 4u : 0u][lane];
-                    const f4 a0 = sc.mat_rec[2u * m0], a1 = sc.mat_rec[2u * m1], a2 = sc.mat_rec[2u * m2], a3 = sc.mat_rec[2u * m3];
-                    c = mk(a0.x, a0.y, a0.z) * c;
-                    if (k >= 2u) c = mk(a1.x, a1.y, a1.z) * c;
-                    if (k >= 3u) c = mk(a2.x, a2.y, a2.z) * c;
-                    if (k >= 4u) c = mk(a3.x, a3.y, a3.z) * c;
-                    k = k >= 4u ? k - 4u : 0u;
-                }
-                StagedRgb out; out.r = c.x; out.g = c.y; out.b = c.z;
-                stage[item] = out;
+                // the path is over; its colour is worked out with those of the other lanes that stand
+                // idle by the time the wave hands out new items (below).  Until then the ray's origin
+                // holds the unit direction it left the scene with and the depth budget the number of
+                // its hits (top bit: it did leave the scene; else it ran out of depth and is black).
+                ray.o = ud;
+                depth_left = n_hits | (h.kind >= 0 ? 0u : 0x80000000u);
                 alive = false;
             }
 #ifdef RTK_TIMES
@@ -1328,11 +1332,41 @@ void render_tiles(KernArgs by_value) {
 #ifdef RTK_TIMES
         const unsigned long long tm3 = __builtin_readcyclecounter();
 #endif
-        // count the finished items against their units (at most four different ones in a wave)
-        unsigned long long dm = __builtin_amdgcn_ballot_w64(done);
+        // Finished items are counted against their units, and their lanes given new items, once
+        // fetch_min_of(MODES) lanes stand idle (or all that are left): both steps cost the wave the
+        // same whether one lane takes part or all.
+        parked = parked || done;
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(!alive);
+        const bool refill = idle != 0ull && ((uint32_t)__builtin_popcountll(idle) >= fetch_min_of(MODES) || (idle | ~__builtin_amdgcn_ballot_w64(true)) == ~0ull);
+        if (refill && parked) {
+            // attenuation * ray_colour(...), innermost product first (src/raytracer.rs:79)
+            // (four entries per round: their fetches overlap, the products keep their order)
+            const RT_CONST_AS KernArgs *ks = args();
+            const RT_CONST_AS f4 *mat_rec = const_ptr<f4>(ks->dsc.mat_rec);
+            // the sky (src/raytracer.rs:82-91), or black
+            V3 c = mk(0.0f, 0.0f, 0.0f);
+            if (depth_left >> 31) c = sky(ray.o, ks->p.gamma != 0u);
+            uint32_t k = depth_left & 0x7fffffffu;
+            while (k != 0u) {
+                const uint32_t m0 = lds.mat_stack[wave][k - 1u][lane];
+                const uint32_t m1 = lds.mat_stack[wave][k >= 2u ? k - 2u : 0u][lane];
+                const uint32_t m2 = lds.mat_stack[wave][k >= 3u ? k - 3u : 0u][lane];
+                const uint32_t m3 = lds.mat_stack[wave][k >= 4u ? k - 4u : 0u][lane];
+                const f4 a0 = mat_rec[2u * m0], a1 = mat_rec[2u * m1], a2 = mat_rec[2u * m2], a3 = mat_rec[2u * m3];
+                c = mk(a0.x, a0.y, a0.z) * c;
+                if (k >= 2u) c = mk(a1.x, a1.y, a1.z) * c;
+                if (k >= 3u) c = mk(a2.x, a2.y, a2.z) * c;
+                if (k >= 4u) c = mk(a3.x, a3.y, a3.z) * c;
+                k = k >= 4u ? k - 4u : 0u;
+            }
+            StagedRgb out; out.r = c.x; out.g = c.y; out.b = c.z;
+            stage[item] = out;
+        }
+        // (at most four different units in a wave)
+        unsigned long long dm = refill ? __builtin_amdgcn_ballot_w64(parked) : 0ull;
         while (dm != 0ull) {
             const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)(item >> ITEM_BITS), __builtin_ctzll(dm));
-            const unsigned long long same = __builtin_amdgcn_ballot_w64(done && (item >> ITEM_BITS) == slot);
+            const unsigned long long same = dm & __builtin_amdgcn_ballot_w64((item >> ITEM_BITS) == slot);
             dm &= ~same;
             const uint32_t left = ring.left[slot] - (uint32_t)__builtin_popcountll(same);
             if (lane == 0u) ring.left[slot] = left;
@@ -1343,7 +1377,7 @@ void render_tiles(KernArgs by_value) {
         const unsigned long long tm4 = __builtin_readcyclecounter();
         tm_fin += tm4 - tm3;
 #endif
-        if (__builtin_amdgcn_ballot_w64(!alive) != 0ull) fetch(!alive);
+        if (refill) { parked = false; fetch(!alive); }
 #ifdef RTK_TIMES
         tm_fetch += __builtin_readcyclecounter() - tm4;
         tm_rest += __builtin_readcyclecounter() - tm1;
