@@ -723,8 +723,7 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
                     // slot order
                     // (a NaN distance ends the walk at once: the next primitive of the step would
                     // replace it, and it need not be one that follows in the list)
-                    bool got_nan = false;
-                    while (bits != 0u && !got_nan) {
+                    while (bits != 0u) {
                         const uint32_t k = (uint32_t)__builtin_ctz(bits);
                         bits &= bits - 1u;
                         const uint32_t slot = run.first + 8u * st + k;
@@ -734,7 +733,7 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
                         const bool closer = walk_test<KIND>(sc, slot, ray, aux, t_min, entry_pos, best_t, best_slot, t);
                         best_t = closer ? t : best_t;
                         best_slot = closer ? slot : best_slot;
-                        got_nan = closer && t != t;
+                        bits = best_t != best_t ? 0u : bits;
                     }
                     // next pending sibling, of this node or of its nearest ancestor that has one
                     const unsigned long long rest = pend >> (8u * L);
