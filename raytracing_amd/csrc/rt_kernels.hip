@@ -1553,9 +1553,10 @@ hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_
         while (unit_px_log2 < 6 && ((uint64_t)p.sample_count << (unit_px_log2 + 1)) <= max_items) ++unit_px_log2;
         // a small launch (one GPU's share of a frame): half as long units, so that a wave still
         // gets a few dozen of them.  Scenes without a tree have short segments and feel the cost of
-        // a unit more (default scene, whole 1080p frame at 64 samples: 7.0 ms with 256-item units,
-        // 5.7 with 512), so there units are halved only below two dozen per wave.
-        const uint64_t want = (sc.modes & 2u) ? 48u : 24u;
+        // a unit more (default scene at 64 samples, 256- against 512-item units: whole 1080p frame
+        // 6.1 / 4.4 ms, half of its bands 3.2 / 2.5, a quarter 1.7 / 1.4, an eighth 1.02 / 0.98), so
+        // there units are halved only below three per wave.
+        const uint64_t want = (sc.modes & 2u) ? 48u : 3u;
         if ((n_tiles << (6 - unit_px_log2)) < want * resident * waves && ((uint64_t)p.sample_count << unit_px_log2) >= 512u)
             --unit_px_log2;
     }

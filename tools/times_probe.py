@@ -12,5 +12,5 @@ r.begin_frame(wl["width"], wl["height"])
 r.timer_start(); r.render(make_params(wl["width"], wl["height"], spp=wl["spp"], sample_begin=0, sample_count=sps)); ms = r.timer_stop()
 out = (C.c_uint64 * 8)(); r._lib.rtdbg_read_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]; r._lib.rtdbg_read_counters(r._ctx, out)
 v = list(out); tot = v[4] + v[7]
-print("ms %.2f segments %d: scan %.3f, shade %.3f, sample completion %.3f, unit accounting and sums %.3f, work-item fetch %.3f of the wave time"
+print("ms %.2f segments %d: scan %.3f, shade %.3f, parking finished paths %.3f, path colours + unit accounting and sums %.3f, work-item fetch %.3f of the wave time"
       % (ms, v[0], v[4] / tot, (v[7] - v[5] - v[6] - v[3]) / tot, v[5] / tot, v[3] / tot, v[6] / tot))
