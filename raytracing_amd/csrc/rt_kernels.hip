@@ -614,13 +614,17 @@ __device__ __forceinline__ bool walk_test(const SceneView &sc, uint32_t slot, co
 }
 
 template <int KIND>
-__device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &run, bool walking,
-                                          TreeTable &tbl, const f4 *tree_top, uint32_t lds_from_level,
+__device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &run, uint32_t r, bool walking,
+                                          TreeTable &tbl, uint32_t &tbl_run, const f4 *tree_top, uint32_t lds_from_level,
                                           const Ray &ray, const RayAux &aux, float t_min, int32_t entry_pos,
                                           float &best_t, uint32_t &best_slot) {
-    // per-level constants where a lane can index them by its own level
+    // per-level constants where a lane can index them by its own level (tbl_run: the run whose
+    // constants the wave's table holds; a scene with one tree writes them once per launch)
+    if (tbl_run != r) {
 #pragma unroll
-    for (uint32_t L = 0; L < DEV_MAX_LEVELS; ++L) { tbl.base[L] = run.lo[8 + L]; tbl.count[L] = run.hi[L]; }
+        for (uint32_t L = 0; L < DEV_MAX_LEVELS; ++L) { tbl.base[L] = run.lo[8 + L]; tbl.count[L] = run.hi[L]; }
+        tbl_run = r;
+    }
     // (S only has to be an upper bound and 1/d only feeds the widened slab test: the hardware's
     // 1-ulp square root and reciprocal do, the square root scaled up by 8 ulp)
     const float S = __builtin_amdgcn_sqrtf(len2(ray.o)) * 1.000001f + __uint_as_float(run.hi[8]);
@@ -634,9 +638,9 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
     // 1/d clamped to +-1e19: a zero component would make plane * inv and k infinities of
     // opposite sign.  With |d| in (1e-6, 1e6) (see scan_tree) a component below 1e-19 moves
     // the ray by less than 2e-13 S over any distance that matters, far inside the pad.
-    const float ix = __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_rcpf(ray.d.x), -1e19f), 1e19f);
-    const float iy = __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_rcpf(ray.d.y), -1e19f), 1e19f);
-    const float iz = __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_rcpf(ray.d.z), -1e19f), 1e19f);
+    const float ix = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(ray.d.x), -1e19f, 1e19f);
+    const float iy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(ray.d.y), -1e19f, 1e19f);
+    const float iz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(ray.d.z), -1e19f, 1e19f);
     const float klx = -((ray.o.x + pad) * ix), kly = -((ray.o.y + pad) * iy), klz = -((ray.o.z + pad) * iz);
     const float khx = -((ray.o.x - pad) * ix), khy = -((ray.o.y - pad) * iy), khz = -((ray.o.z - pad) * iz);
     const uint32_t top = run.n_levels - 1u;
@@ -765,8 +769,8 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
 // cannot be bounded are not in the tree: the run lists them, and every ray tests them first.
 // ----------------------------------------------------------------------
 template <int KIND>
-__device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &run, bool tracing,
-                                          TreeTable &tbl, const f4 *tree_top, uint32_t lds_from_level,
+__device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &run, uint32_t r, bool tracing,
+                                          TreeTable &tbl, uint32_t &tbl_run, const f4 *tree_top, uint32_t lds_from_level,
                                           const Ray &ray, const RayAux &aux, float t_min, Hit &h, uint32_t &ff_shared) {
     const float big = 1e18f;
     const float a = aux.a;
@@ -802,7 +806,7 @@ __device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &ru
                 best_slot = closer ? slot : best_slot;
             }
         }
-        walk_tree<KIND>(sc, run, walking && best_t == best_t, tbl, tree_top, lds_from_level, ray, aux, t_min, h.id,
+        walk_tree<KIND>(sc, run, r, walking && best_t == best_t, tbl, tbl_run, tree_top, lds_from_level, ray, aux, t_min, h.id,
                         best_t, best_slot);
         if (walking && best_t != best_t) {
             listed = true;
@@ -834,7 +838,7 @@ __device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &ru
 // ----------------------------------------------------------------------
 template <int MODES>
 __device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, const RayAux &aux, float t_min, bool tracing,
-                                          TreeTable &tbl, const f4 *tree_top, Hit &h) {
+                                          TreeTable &tbl, uint32_t &tbl_run, const f4 *tree_top, Hit &h) {
     h.t = __builtin_inff();
     h.kind = -1;
     h.slot = 0;
@@ -855,9 +859,9 @@ __device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, c
                 if (!have_cull) { cull = cull_setup(ray, a); have_cull = true; }
                 scan_flat(sc, run, cull, tracing, ray, aux, t_min, h, ff_shared);
             } else if ((MODES & 2) && run.kind == DEV_SPHERE) {
-                scan_tree<DEV_SPHERE>(sc, run, tracing, tbl, tree_top, from, ray, aux, t_min, h, ff_shared);
+                scan_tree<DEV_SPHERE>(sc, run, r, tracing, tbl, tbl_run, tree_top, from, ray, aux, t_min, h, ff_shared);
             } else if (MODES & 2) {
-                scan_tree<DEV_TRI>(sc, run, tracing, tbl, tree_top, from, ray, aux, t_min, h, ff_shared);
+                scan_tree<DEV_TRI>(sc, run, r, tracing, tbl, tbl_run, tree_top, from, ray, aux, t_min, h, ff_shared);
             }
         } else if (run.kind == DEV_SPHERE) {
             // two per trip, both records requested before the first is used: the loop's own scalar
@@ -1261,6 +1265,7 @@ void render_tiles(KernArgs by_value) {
     unsigned long long tm_scan = 0, tm_rest = 0, tm_done = 0, tm_fetch = 0, tm_fin = 0;
 #endif
     fetch(true);
+    uint32_t tbl_run = 0xffffffffu;   // the run whose per-level constants lds.tree[wave] holds (wave-uniform)
     bool parked = false;   // the lane's path is over, its colour not worked out and its item not counted yet
 
     while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
@@ -1281,7 +1286,7 @@ void render_tiles(KernArgs by_value) {
             aux.cheap = cheap_frame && __builtin_amdgcn_ballot_w64(alive && !moderate) == 0ull;
             aux.inv_a = rcp_refined(aux.a);
         }
-        scan_list<MODES>(sc, ray, aux, t_min, alive, lds.tree[wave], lds.tree_top, h);
+        scan_list<MODES>(sc, ray, aux, t_min, alive, lds.tree[wave], tbl_run, lds.tree_top, h);
 #ifdef RTK_TIMES
         const unsigned long long tm1 = __builtin_readcyclecounter();
         tm_scan += tm1 - tm0;

@@ -66,6 +66,10 @@ V = {
  "mul, mul, s_add, s_add": ["v_mul_f32_e32 {d}, {a}, {b}", "v_mul_f32_e32 {d}, {a}, {b}", "s_add_u32 s24, s25, 1", "s_add_u32 s24, s25, 2"] * 2,
  "s_nop 0 only": ["s_nop 0"] * 8,
  "alt fma/s_nop 0": ["v_fma_f32 {d}, {a}, {b}, {b}", "s_nop 0"] * 4,
+ "mul_lo_u32": ["v_mul_lo_u32 {d}, {a}, {b}"] * 8,
+ "mad_u64_u32": ["v_mad_u64_u32 {dp}, s[26:27], {a}, {b}, {bp}"] * 8,
+ "mad_u32_u24": ["v_mad_u32_u24 {d}, {a}, {b}, {b}"] * 8,
+ "lshl_add_u32": ["v_lshl_add_u32 {d}, {a}, 3, {b}"] * 8,
  "mul dependent chain (1 reg)": ["v_mul_f32_e32 {d0}, {d0}, {b}"] * 8,
  "fma dependent chain (1 reg)": ["v_fma_f32 {d0}, {d0}, {b}, {b}"] * 8,
 }
