@@ -60,3 +60,43 @@ def test_origins_and_spheres_around_the_coordinate_limit(renderer, oracle, table
     s.add(Sphere((far - far / 16, far / 32, far / 8), far / 64, Lambertian((0.3, 0.6, 0.3))))
     s.add(Sphere((far, 0.0, far / 2), float(np.float32(2.0 ** -30) * np.float32(far / 2.0 ** 30)), Metal((0.5, 0.5, 0.5), 0.0)))
     check(renderer, oracle, tables, s.flatten(), _camera((far, 0.0, far / 2), 1.0), [make_params(48, 32, spp=2)])
+
+
+@pytest.mark.parametrize("flat_dir", [0.0, 2.0 ** -32, 2.0 ** -31, 2.0 ** -30, 2.0 ** -29, 1e-3])
+@pytest.mark.parametrize("on_face", [False, True])
+def test_cube_slabs_with_tiny_direction_components_and_origins_on_a_face(renderer, oracle, tables, flat_dir, on_face):
+    """the six quotients of Cube::hit (src/geometry/mod.rs:158-206): directions whose y component is
+    tiny or exactly zero (quotients of 2^30 and more, 0/0 on a face plane), and a camera standing in
+    the plane of a cube's face"""
+    from raytracing_amd import Cube, Dielectric, HittableList, Lambertian, Metal, Plane, Sphere, _lib, make_params
+    from tests.test_gpu_tree import _same_with_nans
+    from tests.test_gpu_parity import render_gpu, render_oracle
+    s = HittableList()
+    s.add(Cube((0.0, 0.0, -3.0), 1.0, 1.0, 1.0, Lambertian((0.7, 0.3, 0.7))))
+    s.add(Cube((1.5, 0.25, -2.5), 0.5, 1.5, 0.5, Dielectric((1.0, 1.0, 1.0), 1.5)))
+    s.add(Sphere((-1.5, 0.0, -2.0), 0.4, Metal((0.8, 0.8, 0.8), 0.0)))
+    s.add(Plane((0.0, 1.0, 0.0), (0.0, -0.5, 0.0), Lambertian((0.5, 0.5, 0.5))))
+    origin = (0.5 if on_face else 0.1, 0.5 if on_face else 0.05, 1.0)      # x = 0.5, y = 0.5: faces of the first cube
+    cam = _lib.rt_camera()
+    cam.origin[:] = origin
+    cam.lower_left_corner[:] = (origin[0] - 1.0, origin[1] - flat_dir, origin[2] - 1.0)
+    cam.horizontal[:] = (2.0, 0.0, 0.0)
+    cam.vertical[:] = (0.0, 2.0 * flat_dir, 0.0)
+    cam.u[:] = (1.0, 0.0, 0.0)
+    cam.v[:] = (0.0, 1.0, 0.0)
+    cam.lens_radius = 0.0
+    p = [make_params(48, 32, spp=3)]
+    flat = s.flatten()
+    _same_with_nans(render_gpu(renderer, flat, cam, p), render_oracle(oracle, tables, flat, cam, p), oracle)
+
+
+@pytest.mark.parametrize("far", [2.0 ** 29, 2.0 ** 30 * 0.99, 2.0 ** 30 * 1.01, 2.0 ** 32])
+def test_cubes_around_the_coordinate_limit(renderer, oracle, tables, far):
+    """cube corners on both sides of 2^30"""
+    from raytracing_amd import Cube, HittableList, Lambertian, Metal, Sphere, make_params
+    from tests.test_gpu_parity import check
+    s = HittableList()
+    s.add(Cube((far, 0.0, -far / 4), far / 8, far / 8, far / 8, Metal((0.8, 0.7, 0.6), 0.0)))
+    s.add(Cube((far - far / 16, far / 32, far / 8), far / 64, far / 32, far / 64, Lambertian((0.3, 0.6, 0.3))))
+    s.add(Sphere((far, 0.0, far / 2 - far / 3), far / 16, Lambertian((0.5, 0.5, 0.5))))
+    check(renderer, oracle, tables, s.flatten(), _camera((far - far / 64, 0.0, far / 2), 1.0), [make_params(48, 32, spp=2)])
