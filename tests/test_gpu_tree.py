@@ -410,7 +410,11 @@ def test_fuzz_tree_against_list_order_scan():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_tree_vs_list.py"), "20", "100000"],
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_tree_vs_list.py"), "14", "100000"],
+                         capture_output=True, text=True, timeout=200)
+    assert out.returncode == 0 and "mismatches 0" in out.stdout.splitlines()[-1], out.stdout[-2000:] + out.stderr[-2000:]
+    # and with NaN, infinite, huge or tiny numbers in every scene
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_tree_vs_list.py"), "8", "5100000", "1.0"],
                          capture_output=True, text=True, timeout=200)
     assert out.returncode == 0 and "mismatches 0" in out.stdout.splitlines()[-1], out.stdout[-2000:] + out.stderr[-2000:]
 
