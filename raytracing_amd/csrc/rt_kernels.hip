@@ -2,9 +2,10 @@
 //
 // The launch fills the chip once with resident workgroups; every wavefront takes work units
 // (a few rows of an 8x8 pixel tile x the samples of the launch) from one global queue.  Its
-// work items are (pixel, sample) pairs: as soon as a lane's path ends (sky or depth budget) it
-// takes the next item, whatever pixel that belongs to, and the wave starts its next unit while
-// the longer paths of the last one are still on the way, so waves stay full until the queue is
+// work items are (pixel, sample) pairs: a lane whose path has ended (sky or depth budget) takes
+// the next item, whatever pixel that belongs to - once a third of the wave stands idle, so that
+// the steps in between run for many lanes at a time - and the wave starts its next unit while the
+// longer paths of the last one are still on the way, so waves stay busy until the queue is
 // empty; the per-sample colours are staged in memory and added to each pixel's sum in sample
 // order when the pixel's unit is complete.
 // The closest-hit scan follows the primitive list in the reference's insertion order, run by
@@ -198,7 +199,7 @@ __host__ __device__ constexpr int waves_of(int modes) { return (modes & 2) ? RTK
 #define RTK_OCC 4
 #endif
 #ifndef RTK_OCC0
-#define RTK_OCC0 8           // scenes without long runs: 64 VGPRs, no spills.  Default scene at 1080p, 64 samples:
+#define RTK_OCC0 8           // scenes without long runs: 60 VGPRs, no spills.  Default scene at 1080p, 64 samples:
 #endif                       // 6.40 ms with four waves per SIMD, 5.70 with five, 5.48 with six and with eight
 __host__ __device__ constexpr int occ_of(int modes) { return modes == 0 ? RTK_OCC0 : RTK_OCC; }
 // idle lanes a wave waits for before it counts finished items and hands out new ones
