@@ -1050,7 +1050,7 @@ __device__ __forceinline__ V3 sky(V3 ud, bool gamma) {
 constexpr uint32_t ITEM_BITS = DEV_STAGE_ITEM_BITS;   // item index inside a unit: pixels of the unit x samples of the launch <= 512
 
 // the arguments of render_tiles as they lie in the kernel's argument block
-struct KernArgs { DevScene dsc; rt_camera cam; rt_params p; DevFrame fr; uint32_t n_bands, unit_px_log2; };
+struct KernArgs { DevScene dsc; rt_camera cam; rt_params p; DevFrame fr; uint32_t n_bands, unit_px_log2, stretch_max, stretch_div; };
 
 template <int MODES>
 // Two 8-wave workgroups per CU: four waves per SIMD, at most 128 VGPRs each (some per-item
@@ -1127,6 +1127,8 @@ void render_tiles(KernArgs by_value) {
     // the units after those)
     const uint32_t grid_waves = gridDim.x * (uint32_t)waves_of(MODES);
     uint32_t unit_ahead = blockIdx.x * (uint32_t)waves_of(MODES) + wave;
+    // units the wave may still take from the stretch it was given last (wave-uniform)
+    uint32_t stretch_next = 0u, stretch_end = 0u, asked = 1u;   // asked: units of the request on the way
 
     struct Where { uint32_t i, j, s; };      // column, row from the bottom, sample
     auto where = [&](uint32_t it) {
@@ -1233,12 +1235,25 @@ void render_tiles(KernArgs by_value) {
                 const uint32_t sub_log2 = 6u - unit_px_log2;                  // units per tile, log2
                 const uint32_t n_units = (tiles_x * k->n_bands) << sub_log2;
                 const uint32_t sample_count = k->p.sample_count;
-                const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit_ahead);
-                if (u >= n_units) { queue_empty = true; break; }
-                // (a launch with no more units than waves never asks the counter: thousands of
-                // requests for nothing take 30 us to answer)
-                if (grid_waves >= n_units) unit_ahead = n_units;
-                else if (lane == 0u) unit_ahead = grid_waves + atomicAdd(k->fr.queue, 1u);
+                uint32_t u;
+                if (stretch_next < stretch_end) {
+                    u = stretch_next++;
+                } else {
+                    u = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit_ahead);
+                    if (u >= n_units) { queue_empty = true; break; }
+                    // The counter hands out stretches of consecutive units, one request per stretch (it
+                    // answers about 90 requests per microsecond; with one unit per request a million
+                    // triangles at 4K ask 21 times per microsecond): a few units while much is left,
+                    // single units afterwards (see rtk_launch_render).  A wave's first unit, by
+                    // position, is a stretch of one.
+                    if (u >= grid_waves) { stretch_next = u + 1u; stretch_end = min(u + asked, n_units); }
+                    const uint32_t left = n_units - u;
+                    asked = min(max(left / (grid_waves * k->stretch_div), 1u), k->stretch_max);
+                    // (a launch with no more units than waves never asks the counter: thousands of
+                    // requests for nothing take 30 us to answer)
+                    if (grid_waves >= n_units) unit_ahead = n_units;
+                    else if (lane == 0u) unit_ahead = grid_waves + atomicAdd(k->fr.queue, asked);
+                }
                 const uint32_t t = u >> sub_log2, sub = u & ((1u << sub_log2) - 1u);
                 const uint32_t by = t / tiles_x, tx = t - by * tiles_x;
                 const uint32_t band = k->p.band_begin + by * k->p.band_stride;
@@ -1568,12 +1583,21 @@ hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_
     }
     if (((uint64_t)p.sample_count << unit_px_log2) > max_items) return hipErrorInvalidValue;
     const uint64_t n_units = n_tiles << (6 - unit_px_log2);
-    if (n_units >= 0xffffffffull - 2u * resident * waves) return hipErrorInvalidValue;   // unit numbers handed out: below n_units + 2 x waves
+    if (n_units >= 0xffffffffull - 64u * resident * waves) return hipErrorInvalidValue;   // unit numbers handed out: below n_units + waves x (1 + stretch)
     // as many workgroups as the chip holds, fewer when there are not that many work units
     const uint64_t groups = std::max<uint64_t>(1u, std::min<uint64_t>(resident, (n_units + waves - 1u) / waves));
     dim3 grid((uint32_t)groups, 1, 1), block(waves * 64, 1, 1);
     const uint32_t r = (uint32_t)unit_px_log2;
-    const rtk::KernArgs ka{sc, cam, p, fr, n_bands, r};
+    // Units per request to the queue counter: (units left) / (stretch_div x waves), at most stretch_max.
+    // Long stretches end a launch unevenly even when they shrink towards its end (the default scene
+    // at 1080p, 32 units per wave: 8.0 ms with stretches of up to 8 from the start, 4.5 without; a
+    // wave's stretch on the way was asked for a stretch earlier), so they are used only while a wave
+    // still has 32 units and more to come: 10,000 spheres 4K -0.8 %, a million triangles -1.4 %.
+    // (development aids: RT_HIP_STRETCH_MAX, RT_HIP_STRETCH_DIV)
+    static const char *max_env = std::getenv("RT_HIP_STRETCH_MAX"), *div_env = std::getenv("RT_HIP_STRETCH_DIV");
+    const uint32_t stretch_max = max_env ? (uint32_t)std::min(32, std::max(1, std::atoi(max_env))) : 8u;
+    const uint32_t stretch_div = div_env ? (uint32_t)std::max(1, std::atoi(div_env)) : 32u;
+    const rtk::KernArgs ka{sc, cam, p, fr, n_bands, r, stretch_max, stretch_div};
     switch (sc.modes & 3u) {
     case 0: hipLaunchKernelGGL(rtk::render_tiles<0>, grid, block, 0, stream, ka); break;
     case 1: hipLaunchKernelGGL(rtk::render_tiles<1>, grid, block, 0, stream, ka); break;

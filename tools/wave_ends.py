@@ -16,7 +16,7 @@ r.timer_start(); r.render(p); ms = r.timer_stop()
 lib = r._lib
 lib.rtdbg_stage_ptr.restype = C.c_void_p; lib.rtdbg_stage_ptr.argtypes = [C.c_void_p]
 ptr = lib.rtdbg_stage_ptr(r._ctx)
-n = 4096
+n = int(os.environ.get("WAVES", "4096"))   # waves of the launch (8192 for a scene without a tree)
 STRIDE = 24576 // 8          # every wave logs at the start of its 24 KiB of the staging ring
 buf = (C.c_uint64 * (STRIDE * n))()
 import ctypes
