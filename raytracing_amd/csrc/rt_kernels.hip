@@ -1050,7 +1050,7 @@ __device__ __forceinline__ V3 sky(V3 ud, bool gamma) {
 constexpr uint32_t ITEM_BITS = DEV_STAGE_ITEM_BITS;   // item index inside a unit: pixels of the unit x samples of the launch <= 512
 
 // the arguments of render_tiles as they lie in the kernel's argument block
-struct KernArgs { DevScene dsc; rt_camera cam; rt_params p; DevFrame fr; uint32_t n_bands, unit_px_log2, stretch_max, stretch_div; };
+struct KernArgs { DevScene dsc; rt_camera cam; rt_params p; DevFrame fr; uint32_t n_bands, unit_px_log2, stretch_unit; };
 
 template <int MODES>
 // Two 8-wave workgroups per CU: four waves per SIMD, at most 128 VGPRs each (some per-item
@@ -1236,7 +1236,9 @@ void render_tiles(KernArgs by_value) {
                 const uint32_t n_units = (tiles_x * k->n_bands) << sub_log2;
                 const uint32_t sample_count = k->p.sample_count;
                 uint32_t u;
-                if (stretch_next < stretch_end) {
+                // (only the kernels with a tree: a scene without one has short launches, and the
+                // three wave-uniform values cost its kernel more than the requests they save)
+                if ((MODES & 2) && stretch_next < stretch_end) {
                     u = stretch_next++;
                 } else {
                     u = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit_ahead);
@@ -1246,9 +1248,11 @@ void render_tiles(KernArgs by_value) {
                     // triangles at 4K ask 21 times per microsecond): a few units while much is left,
                     // single units afterwards (see rtk_launch_render).  A wave's first unit, by
                     // position, is a stretch of one.
-                    if (u >= grid_waves) { stretch_next = u + 1u; stretch_end = min(u + asked, n_units); }
-                    const uint32_t left = n_units - u;
-                    asked = min(max(left / (grid_waves * k->stretch_div), 1u), k->stretch_max);
+                    if (MODES & 2) {
+                        if (u >= grid_waves) { stretch_next = u + 1u; stretch_end = min(u + asked, n_units); }
+                        const uint32_t left = n_units - u, per = k->stretch_unit;   // per: 32 units for every wave
+                        asked = left >= 8u * per ? 8u : left >= 4u * per ? 4u : left >= 2u * per ? 2u : 1u;
+                    }
                     // (a launch with no more units than waves never asks the counter: thousands of
                     // requests for nothing take 30 us to answer)
                     if (grid_waves >= n_units) unit_ahead = n_units;
@@ -1588,16 +1592,14 @@ hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_
     const uint64_t groups = std::max<uint64_t>(1u, std::min<uint64_t>(resident, (n_units + waves - 1u) / waves));
     dim3 grid((uint32_t)groups, 1, 1), block(waves * 64, 1, 1);
     const uint32_t r = (uint32_t)unit_px_log2;
-    // Units per request to the queue counter: (units left) / (stretch_div x waves), at most stretch_max.
-    // Long stretches end a launch unevenly even when they shrink towards its end (the default scene
-    // at 1080p, 32 units per wave: 8.0 ms with stretches of up to 8 from the start, 4.5 without; a
-    // wave's stretch on the way was asked for a stretch earlier), so they are used only while a wave
-    // still has 32 units and more to come: 10,000 spheres 4K -0.8 %, a million triangles -1.4 %.
-    // (development aids: RT_HIP_STRETCH_MAX, RT_HIP_STRETCH_DIV)
-    static const char *max_env = std::getenv("RT_HIP_STRETCH_MAX"), *div_env = std::getenv("RT_HIP_STRETCH_DIV");
-    const uint32_t stretch_max = max_env ? (uint32_t)std::min(32, std::max(1, std::atoi(max_env))) : 8u;
-    const uint32_t stretch_div = div_env ? (uint32_t)std::max(1, std::atoi(div_env)) : 32u;
-    const rtk::KernArgs ka{sc, cam, p, fr, n_bands, r, stretch_max, stretch_div};
+    // Units per request to the queue counter: 8, 4 or 2 while every wave still has 8, 4 or 2 times 32
+    // units to come, else 1.  Long stretches end a launch unevenly even when they shrink towards its
+    // end (the default scene at 1080p, 32 units per wave: 8.0 ms with stretches of up to 8 from the
+    // start, 4.5 without; a wave's stretch on the way was asked for a stretch earlier), so they are
+    // used only while much is left, and only by the kernels with a tree: 10,000 spheres 4K -0.4 %, a
+    // million triangles -1 %.
+    const uint64_t stretch_unit = std::min<uint64_t>(32u * groups * waves, 0x1fffffffu);
+    const rtk::KernArgs ka{sc, cam, p, fr, n_bands, r, (uint32_t)stretch_unit};
     switch (sc.modes & 3u) {
     case 0: hipLaunchKernelGGL(rtk::render_tiles<0>, grid, block, 0, stream, ka); break;
     case 1: hipLaunchKernelGGL(rtk::render_tiles<1>, grid, block, 0, stream, ka); break;
