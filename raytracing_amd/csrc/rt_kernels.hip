@@ -202,6 +202,11 @@ __host__ __device__ constexpr int waves_of(int modes) { return (modes & 2) ? RTK
 #define RTK_OCC0 8           // scenes without long runs: 60 VGPRs, no spills.  Default scene at 1080p, 64 samples:
 #endif                       // 6.40 ms with four waves per SIMD, 5.70 with five, 5.48 with six and with eight
 __host__ __device__ constexpr int occ_of(int modes) { return modes == 0 ? RTK_OCC0 : RTK_OCC; }
+// What the compiler is told: one wave less for the kernel without long runs.  At "eight waves" it
+// keeps to 80 scalar registers and parks 30 wave-uniform values in lanes of vector registers; told
+// seven it takes 94 (14 parked) and still fits eight waves per SIMD (64 VGPRs, 96 SGPRs, 20 KB of LDS
+// per workgroup): default scene -1.4 %.  The launch asks the runtime what really fits (blocks_per_cu).
+__host__ __device__ constexpr int occ_hint_of(int modes) { return modes == 0 ? RTK_OCC0 - 1 : RTK_OCC; }
 // idle lanes a wave waits for before it counts finished items and hands out new ones
 // (64-sample launches of the whole frame, 1 / 16 / 24 / 32 lanes: default scene 1080p 4.97 / 4.70 / 4.57 /
 // 4.58 ms; with a tree 8 / 16 / 20 / 24 / 32 lanes: 10,000 spheres 4K 107.8 / 105.6 / 105.6 / 106.4 /
@@ -1058,7 +1063,7 @@ template <int MODES>
 // waves per SIMD without spills (one 12-wave workgroup per CU) -14 %, 4-wave workgroups with
 // a 16 KB tree copy -5 %, 16-wave workgroups the same, 96 VGPRs for five waves per SIMD -40 %;
 // 6- or 10-wave workgroups fit only once per CU.
-__global__ __launch_bounds__(waves_of(MODES) * 64, occ_of(MODES))
+__global__ __launch_bounds__(waves_of(MODES) * 64, occ_hint_of(MODES))
 void render_tiles(KernArgs by_value) {
     __shared__ Lds<MODES> lds;
 #ifdef RTK_WAVE_ENDS
@@ -1557,15 +1562,37 @@ hipError_t rtk_launch_pack_bands(const float4 *accum, uint32_t *out, uint32_t W,
                        n_bands);
     return hipGetLastError();
 }
-uint32_t rtk_resident_waves(uint32_t n_cus) { return n_cus * 4u * (RTK_OCC > RTK_OCC0 ? RTK_OCC : RTK_OCC0); }
+// workgroups of render_tiles<modes> that fit one CU, asked once per process (the same on every GPU of a node)
+static uint32_t blocks_per_cu(uint32_t modes) {
+    static std::once_flag once;
+    static int fit[4] = {0, 0, 0, 0};
+    std::call_once(once, [] {
+        const void *kernels[4] = {(const void *)rtk::render_tiles<0>, (const void *)rtk::render_tiles<1>,
+                                  (const void *)rtk::render_tiles<2>, (const void *)rtk::render_tiles<3>};
+        for (int m = 0; m < 4; ++m) {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernels[m], rtk::waves_of(m) * 64, 0) != hipSuccess || n <= 0)
+                n = 4 * rtk::occ_hint_of(m) / rtk::waves_of(m);      // what the compiler was told
+            fit[m] = n;
+        }
+    });
+    return (uint32_t)fit[modes & 3u];
+}
+uint32_t rtk_resident_waves(uint32_t n_cus) {
+    (void)blocks_per_cu(0u);   // asked here, when a context is made, so that no launch has to
+    return n_cus * 4u * (RTK_OCC > RTK_OCC0 ? RTK_OCC : RTK_OCC0);
+}
 hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_params &p,
                              const DevFrame &fr, uint32_t n_bands, uint32_t n_cus, uint32_t stage_waves,
                              int unit_px_log2, hipStream_t stream) {
     const uint32_t waves = (uint32_t)rtk::waves_of((int)(sc.modes & 3u));
     const uint32_t tiles_x = (p.width + rtk::TILE - 1u) / rtk::TILE;
     const uint64_t n_tiles = (uint64_t)tiles_x * n_bands;
-    // workgroups the chip holds at once, and the staging ring has room for
-    const uint64_t resident = std::min<uint64_t>((uint64_t)n_cus * (4u * rtk::occ_of((int)(sc.modes & 3u)) / waves), stage_waves / waves);
+    // workgroups the chip holds at once (what the kernel is written for, and no more than the runtime
+    // says fit a CU: a workgroup that is not resident would start its first unit when another one ends),
+    // and the staging ring has room for
+    const uint64_t resident = std::min<uint64_t>((uint64_t)n_cus * std::min<uint32_t>(4u * rtk::occ_of((int)(sc.modes & 3u)) / waves, blocks_per_cu(sc.modes & 3u)),
+                                                 stage_waves / waves);
     if (p.sample_count > DEV_SAMPLE_CHUNK || p.width > 65536u || p.height > 65536u || resident == 0u) return hipErrorInvalidValue;
     const uint64_t max_items = 1ull << DEV_STAGE_ITEM_BITS;    // a unit's colours must fit one ring slot
     // Pixels of a tile per work unit (part of a row, or whole rows): the fewest that still give a
