@@ -141,54 +141,72 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16 __attribute__((ext_vector_type(16)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u16v __attribute__((ext_vector_type(16)));
+typedef uint32_t u8v __attribute__((ext_vector_type(8)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 #define RT_CONST_AS __attribute__((address_space(4)))
 template <typename T, typename S>
 __device__ __forceinline__ const RT_CONST_AS T *const_ptr(const S *p) {
     return (const RT_CONST_AS T *)(uintptr_t)p;
 }
+// The scene's arrays.  Only the place of the DevScene in the kernel's argument block is kept in
+// registers: a part of the scan fetches the address of an array where it starts to use it (a
+// scalar load that hits the scalar cache), through a pointer the compiler cannot trace back, so
+// that a dozen addresses do not sit in scalar registers through the whole scan - with the loop's
+// own wave-uniform state they do not fit, and what does not fit is parked in lanes of vector
+// registers at a vector instruction per use.
 struct SceneView {
-    const RT_CONST_AS u16v *runs;         // two per DevRun
-    const RT_CONST_AS f4 *sph_geom, *planes, *cubes, *tris, *mat_rec;
-    const RT_CONST_AS f16 *cull_rec;      // RUN_FLAT: two per step of eight records
-    const RT_CONST_AS f4 *tree_rec;       // RUN_TREE: twelve per step of eight boxes
-    const RT_CONST_AS uint32_t *sph_mat, *sph_id, *tri_id, *order;
-    uint32_t n_runs, need_ff_shared;
-    uint32_t lds_run, lds_level, lds_first;
+    const RT_CONST_AS DevScene *d;
+    uint32_t n_runs;
+    bool lazy;                   // false (the kernel for scenes without long runs, where they do fit): addresses are
+                                 // fetched wherever the compiler likes, once
     unsigned long long *stats;   // fr.segments; slots 1..7 are instrumentation (RTK_STATS builds)
+    __device__ __forceinline__ const RT_CONST_AS DevScene *at() const {
+        const RT_CONST_AS DevScene *p = d;
+        if (lazy) asm volatile("" : "+s"(p));
+        return p;
+    }
+    __device__ __forceinline__ const RT_CONST_AS u8v *runs() const { return const_ptr<u8v>(at()->runs); }   // four per DevRun
+    __device__ __forceinline__ const RT_CONST_AS f4 *sph_geom() const { return const_ptr<f4>(at()->sph_geom); }
+    __device__ __forceinline__ const RT_CONST_AS f4 *planes() const { return const_ptr<f4>(at()->planes); }
+    __device__ __forceinline__ const RT_CONST_AS f4 *cubes() const { return const_ptr<f4>(at()->cubes); }
+    __device__ __forceinline__ const RT_CONST_AS f4 *tris() const { return const_ptr<f4>(at()->tris); }
+    __device__ __forceinline__ const RT_CONST_AS f4 *mat_rec() const { return const_ptr<f4>(at()->mat_rec); }
+    __device__ __forceinline__ const RT_CONST_AS f16 *cull_rec() const { return const_ptr<f16>(at()->cull_rec); }   // RUN_FLAT: two per step of eight records
+    __device__ __forceinline__ const RT_CONST_AS f4 *tree_rec() const { return const_ptr<f4>(at()->tree_rec); }     // RUN_TREE: twelve per step of eight boxes
+    __device__ __forceinline__ const RT_CONST_AS uint32_t *sph_mat() const { return const_ptr<uint32_t>(at()->sph_mat); }
+    __device__ __forceinline__ const RT_CONST_AS uint32_t *sph_id() const { return const_ptr<uint32_t>(at()->sph_id); }
+    __device__ __forceinline__ const RT_CONST_AS uint32_t *tri_id() const { return const_ptr<uint32_t>(at()->tri_id); }
+    __device__ __forceinline__ const RT_CONST_AS uint32_t *order() const { return const_ptr<uint32_t>(at()->order); }
+    __device__ __forceinline__ uint32_t need_ff_shared() const { return at()->need_ff_shared; }
+    // lds_run, lds_level, lds_first, lds_count
+    __device__ __forceinline__ u4v lds() const { return *(const RT_CONST_AS u4v *)&at()->lds_run; }
 };
-__device__ __forceinline__ SceneView view_of(const RT_CONST_AS DevScene &sc, unsigned long long *stats) {
+__device__ __forceinline__ SceneView view_of(const RT_CONST_AS DevScene *d, unsigned long long *stats, bool lazy) {
     SceneView v;
+    v.d = d;
+    v.lazy = lazy;
+    v.n_runs = d->n_runs;
     v.stats = stats;
-    v.runs = const_ptr<u16v>(sc.runs);
-    v.sph_geom = const_ptr<f4>(sc.sph_geom);
-    v.planes = const_ptr<f4>(sc.planes);
-    v.cubes = const_ptr<f4>(sc.cubes);
-    v.tris = const_ptr<f4>(sc.tris);
-    v.mat_rec = const_ptr<f4>(sc.mat_rec);
-    v.cull_rec = const_ptr<f16>(sc.cull_rec);
-    v.tree_rec = const_ptr<f4>(sc.tree_rec);
-    v.sph_mat = const_ptr<uint32_t>(sc.sph_mat);
-    v.sph_id = const_ptr<uint32_t>(sc.sph_id);
-    v.tri_id = const_ptr<uint32_t>(sc.tri_id);
-    v.order = const_ptr<uint32_t>(sc.order);
-    v.n_runs = sc.n_runs;
-    v.need_ff_shared = sc.need_ff_shared;
-    v.lds_run = sc.lds_run; v.lds_level = sc.lds_level; v.lds_first = sc.lds_first;
     return v;
 }
-// the words of a DevRun as the two scalar loads deliver them
+// A DevRun: its first eight words in scalar registers (one scalar load); the others are read
+// where a long run needs them (all 32 at once would push as many wave-uniform values of the
+// loop out of the scalar register file for every run of the list)
 struct RunView {
     uint32_t kind, first, count, id0, mode, n_levels, top_steps, order_base;
-    u16v lo, hi;
-    __device__ __forceinline__ uint32_t level_base(uint32_t L) const { return lo[8 + L]; }
-    __device__ __forceinline__ float level_keep(uint32_t L) const { return __uint_as_float(hi[L]); }   // ball levels only
+    const RT_CONST_AS uint32_t *words;
+    __device__ __forceinline__ uint32_t level_base0() const { return words[8]; }
+    __device__ __forceinline__ float level_keep0() const { return __uint_as_float(words[16]); }   // RUN_FLAT
+    // reach, 1 / (2 smallest radius), primitives outside the tree
+    __device__ __forceinline__ u4v tail() const { return *(const RT_CONST_AS u4v *)(words + 24); }
 };
 __device__ __forceinline__ RunView load_run(const SceneView &sc, uint32_t r) {
     RunView v;
-    v.lo = sc.runs[2 * r];
-    v.hi = sc.runs[2 * r + 1];
-    v.kind = v.lo.s0; v.first = v.lo.s1; v.count = v.lo.s2; v.id0 = v.lo.s3;
-    v.mode = v.lo.s4; v.n_levels = v.lo.s5; v.top_steps = v.lo.s6; v.order_base = v.lo.s7;
+    const RT_CONST_AS u8v *rec = sc.runs() + 4 * r;
+    const u8v head = rec[0];
+    v.words = (const RT_CONST_AS uint32_t *)rec;
+    v.kind = head.s0; v.first = head.s1; v.count = head.s2; v.id0 = head.s3;
+    v.mode = head.s4; v.n_levels = head.s5; v.top_steps = head.s6; v.order_base = head.s7;
     return v;
 }
 
@@ -359,22 +377,22 @@ __device__ __forceinline__ bool sphere_closer(const f4 g, const Ray &ray, const 
 }
 // front_face of a sphere hit at distance t, src/geometry/mod.rs:81-86,30-33
 __device__ __forceinline__ bool sphere_front_face(const SceneView &sc, uint32_t slot, const Ray &ray, float t, bool cheap) {
-    const f4 g = sc.sph_geom[slot];
+    const f4 g = sc.sph_geom()[slot];
     V3 p = ray.o + ray.d * t;
     V3 outward = div3(p - mk(g.x, g.y, g.z), g.w, cheap);
     return dot(ray.d, outward) < 0.0f;
 }
-// one sphere of a list-order scan (g: its record, sc.sph_geom[slot])
+// one sphere of a list-order scan (g: its record)
 __device__ __forceinline__ void sphere_exact(const SceneView &sc, const f4 g, uint32_t slot, int32_t id, const Ray &ray,
                                              const RayAux &aux, float t_min, Hit &h, uint32_t &ff_shared) {
     float root;
     if (!sphere_closer(g, ray, aux, t_min, h.t, [&]() { return id; }, [&]() { return h.id; }, root)) return;
     h.t = root; h.kind = DEV_SPHERE; h.slot = slot; h.id = id;
-    if (sc.need_ff_shared) ff_shared = sphere_front_face(sc, slot, ray, root, aux.cheap) ? 1u : 0u;
+    if (sc.need_ff_shared()) ff_shared = sphere_front_face(sc, slot, ray, root, aux.cheap) ? 1u : 0u;
 }
 __device__ __forceinline__ void sphere_exact(const SceneView &sc, uint32_t slot, int32_t id, const Ray &ray,
                                              const RayAux &aux, float t_min, Hit &h, uint32_t &ff_shared) {
-    sphere_exact(sc, sc.sph_geom[slot], slot, id, ray, aux, t_min, h, ff_shared);
+    sphere_exact(sc, sc.sph_geom()[slot], slot, id, ray, aux, t_min, h, ff_shared);
 }
 // same selections as `m = a > b ? a : b; m > c ? m : c` (and < for min): with a NaN operand the
 // results may differ from a fused max3, so they are spelled out
@@ -384,11 +402,11 @@ __device__ __forceinline__ float min3(float a, float b, float c) { float m = a <
 // bounding-box gate that keeps the f32 barycentric test from accepting points far outside
 // a sliver or an edge-on triangle
 template <class ThisPos, class HolderPos>
-__device__ __forceinline__ bool tri_closer(const SceneView &sc, uint32_t slot, const Ray &ray, float t_min, float closest,
+__device__ __forceinline__ bool tri_closer(const RT_CONST_AS f4 *tris, uint32_t slot, const Ray &ray, float t_min, float closest,
                                            ThisPos this_pos, HolderPos holder_pos, float &t) {
-    const f4 v0 = sc.tris[3 * slot];
-    const f4 e1 = sc.tris[3 * slot + 1];
-    const f4 e2 = sc.tris[3 * slot + 2];
+    const f4 v0 = tris[3 * slot];
+    const f4 e1 = tris[3 * slot + 1];
+    const f4 e2 = tris[3 * slot + 2];
     // all three fetched now: left to itself the compiler fetches v0 only after the determinant
     // test, a second round trip to memory for most triangles that get this far
     asm volatile("" ::"v"(v0.x), "v"(e1.x), "v"(e2.x));
@@ -423,8 +441,9 @@ __device__ __forceinline__ bool tri_closer(const SceneView &sc, uint32_t slot, c
 }
 // front_face of a triangle hit: outward normal unit(cross(e1, e2))
 __device__ __forceinline__ bool tri_front_face(const SceneView &sc, uint32_t slot, const Ray &ray) {
-    const f4 e1 = sc.tris[3 * slot + 1];
-    const f4 e2 = sc.tris[3 * slot + 2];
+    const RT_CONST_AS f4 *tris = sc.tris();
+    const f4 e1 = tris[3 * slot + 1];
+    const f4 e2 = tris[3 * slot + 2];
     V3 outward = unit(cross(mk(e1.x, e1.y, e1.z), mk(e2.x, e2.y, e2.z)));
     return dot(ray.d, outward) < 0.0f;
 }
@@ -432,9 +451,9 @@ __device__ __forceinline__ bool tri_front_face(const SceneView &sc, uint32_t slo
 __device__ __forceinline__ void tri_exact(const SceneView &sc, uint32_t slot, int32_t id, const Ray &ray,
                                           float t_min, Hit &h, uint32_t &ff_shared) {
     float t;
-    if (!tri_closer(sc, slot, ray, t_min, h.t, [&]() { return id; }, [&]() { return h.id; }, t)) return;
+    if (!tri_closer(sc.tris(), slot, ray, t_min, h.t, [&]() { return id; }, [&]() { return h.id; }, t)) return;
     h.t = t; h.kind = DEV_TRI; h.slot = slot; h.id = id;
-    if (sc.need_ff_shared) ff_shared = tri_front_face(sc, slot, ray) ? 1u : 0u;
+    if (sc.need_ff_shared()) ff_shared = tri_front_face(sc, slot, ray) ? 1u : 0u;
 }
 
 // ----------------------------------------------------------------------
@@ -524,7 +543,7 @@ __device__ __forceinline__ void leaf_exact(const SceneView &sc, const RunView &r
         RTK_COUNT(sc, 4, 1);
         const uint32_t slot = run.first + first_in_run + k;
         const int32_t id = list_order ? (int32_t)(run.id0 + first_in_run + k)
-                                      : (int32_t)(KIND == DEV_SPHERE ? sc.sph_id[slot] : sc.tri_id[slot]);
+                                      : (int32_t)(KIND == DEV_SPHERE ? sc.sph_id()[slot] : sc.tri_id()[slot]);
         if ((lane_bits >> k) & 1u) {
             if (KIND == DEV_SPHERE) sphere_exact(sc, slot, id, ray, aux, t_min, h, ff_shared);
             else tri_exact(sc, slot, id, ray, t_min, h, ff_shared);
@@ -546,10 +565,10 @@ __device__ __forceinline__ void scan_flat(const SceneView &sc, const RunView &ru
     // Every intermediate of Sphere::hit stays below 2 a S^2, S = |o| + reach >= |o - c| + |r| for the
     // run's bounded spheres.  Where that may overflow, the discriminant can come out as inf - inf and
     // the reference accepts the NaN root of a sphere the ray passes far from: nothing is rejected then.
-    const float S = __builtin_amdgcn_sqrtf(cull.oo) * 1.000001f + __uint_as_float(run.hi[8]);
+    const float S = __builtin_amdgcn_sqrtf(cull.oo) * 1.000001f + __uint_as_float(run.tail().x);
     const float oo = aux.a * (S * S) < 1e37f ? cull.oo : __builtin_nanf("");
-    const float oo_keep = tracing ? oo * run.level_keep(0) : __builtin_inff();
-    const RT_CONST_AS f16 *rec = sc.cull_rec + 2u * run.level_base(0);
+    const float oo_keep = tracing ? oo * run.level_keep0() : __builtin_inff();
+    const RT_CONST_AS f16 *rec = sc.cull_rec() + 2u * run.level_base0();
     const uint32_t trips = run.top_steps / 2u;
     f16 a0 = rec[0], a1 = rec[1];
     for (uint32_t b = 0; b < trips; ++b) {
@@ -610,34 +629,40 @@ __device__ __forceinline__ void scan_flat(const SceneView &sc, const RunView &ru
 // the walk.  Exact test of the primitive in `slot` against that state.
 constexpr uint32_t NO_SLOT = 0xffffffffu;
 template <int KIND>
-__device__ __forceinline__ bool walk_test(const SceneView &sc, uint32_t slot, const Ray &ray, const RayAux &aux,
+__device__ __forceinline__ bool walk_test(const RT_CONST_AS f4 *geom, const RT_CONST_AS uint32_t *by_slot, uint32_t slot,
+                                          const Ray &ray, const RayAux &aux,
                                           float t_min, int32_t entry_pos, float best_t, uint32_t best_slot, float &t) {
-    const RT_CONST_AS uint32_t *by_slot = KIND == DEV_SPHERE ? sc.sph_id : sc.tri_id;
     auto this_pos = [&]() { return (int32_t)by_slot[slot]; };
     auto holder_pos = [&]() { return best_slot == NO_SLOT ? entry_pos : (int32_t)by_slot[best_slot]; };
-    if (KIND == DEV_SPHERE) return sphere_closer(sc.sph_geom[slot], ray, aux, t_min, best_t, this_pos, holder_pos, t);
-    return tri_closer(sc, slot, ray, t_min, best_t, this_pos, holder_pos, t);
+    if (KIND == DEV_SPHERE) return sphere_closer(geom[slot], ray, aux, t_min, best_t, this_pos, holder_pos, t);
+    return tri_closer(geom, slot, ray, t_min, best_t, this_pos, holder_pos, t);
 }
 
 template <int KIND>
 __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &run, uint32_t r, bool walking,
                                           TreeTable &tbl, uint32_t &tbl_run, const f4 *tree_top, uint32_t lds_from_level,
+                                          const RT_CONST_AS f4 *geom, const RT_CONST_AS uint32_t *by_slot,
                                           const Ray &ray, const RayAux &aux, float t_min, int32_t entry_pos,
                                           float &best_t, uint32_t &best_slot) {
     // per-level constants where a lane can index them by its own level (tbl_run: the run whose
     // constants the wave's table holds; a scene with one tree writes them once per launch)
     if (tbl_run != r) {
-#pragma unroll
-        for (uint32_t L = 0; L < DEV_MAX_LEVELS; ++L) { tbl.base[L] = run.lo[8 + L]; tbl.count[L] = run.hi[L]; }
+        // (lane L copies the two words of level L)
+        const uint32_t L = (uint32_t)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        const uint32_t *w = (const uint32_t *)(uintptr_t)run.words;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (L < DEV_MAX_LEVELS) { tbl.base[L] = w[8u + L]; tbl.count[L] = w[16u + L]; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         tbl_run = r;
     }
+    const u4v tail = run.tail();
     // (S only has to be an upper bound and 1/d only feeds the widened slab test: the hardware's
     // 1-ulp square root and reciprocal do, the square root scaled up by 8 ulp)
-    const float S = __builtin_amdgcn_sqrtf(len2(ray.o)) * 1.000001f + __uint_as_float(run.hi[8]);
+    const float S = __builtin_amdgcn_sqrtf(len2(ray.o)) * 1.000001f + __uint_as_float(tail.x);
     float reach_pad = 0.0f;
     if (KIND == DEV_SPHERE) {
         const float kS = S * (1.0f / 524288.0f);
-        reach_pad = __builtin_fminf(S * 1.3811e-3f, kS * S * __uint_as_float(run.hi[9]));
+        reach_pad = __builtin_fminf(S * 1.3811e-3f, kS * S * __uint_as_float(tail.y));
     }
     const float pad = S * (1.0f / 131072.0f) + reach_pad;
     // slab test constants: t = plane * inv + k, k = -(o -+ pad) * inv.
@@ -650,7 +675,8 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
     const float klx = -((ray.o.x + pad) * ix), kly = -((ray.o.y + pad) * iy), klz = -((ray.o.z + pad) * iz);
     const float khx = -((ray.o.x - pad) * ix), khy = -((ray.o.y - pad) * iy), khz = -((ray.o.z - pad) * iz);
     const uint32_t top = run.n_levels - 1u;
-    const RT_CONST_AS f4 *nodes = sc.tree_rec;
+    const RT_CONST_AS f4 *nodes = sc.tree_rec();
+    const uint32_t lds_first = sc.lds().z;
     // no hit is accepted in front of t_min; the bound lies a little below it, so that a box
     // holding a hit at exactly t_min (and at closest_so_far, a tie) keeps an interval of its own
     // (0 for the usual positive t_min: entry distances that are not negative order like their
@@ -674,7 +700,7 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
                 const uint32_t at = tbl.base[L] + 12u * st;
                 f4 nd[12];
                 if (L >= lds_from_level) {
-                    const f4 *src = tree_top + (at - sc.lds_first);
+                    const f4 *src = tree_top + (at - lds_first);
 #pragma unroll
                     for (int q = 0; q < 12; ++q) nd[q] = src[q];
                 } else {
@@ -740,7 +766,7 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
                         RTK_COUNT(sc, 4, 1);
                         RTK_COUNT_ANY(sc, 7, 1);
                         float t;
-                        const bool closer = walk_test<KIND>(sc, slot, ray, aux, t_min, entry_pos, best_t, best_slot, t);
+                        const bool closer = walk_test<KIND>(geom, by_slot, slot, ray, aux, t_min, entry_pos, best_t, best_slot, t);
                         best_t = closer ? t : best_t;
                         best_slot = closer ? slot : best_slot;
                         bits = best_t != best_t ? 0u : bits;
@@ -790,7 +816,7 @@ __device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &ru
         // At the other end, below 1e-20 its products may underflow and the relative bound on the
         // discriminant that the pad of the boxes is made from no longer holds.  (Above it a sphere
         // with a |o - c|^2 < 1e-36 has the origin inside its padded box and is never skipped.)
-        const float S = __builtin_amdgcn_sqrtf(len2(ray.o)) * 1.000001f + __uint_as_float(run.hi[8]);
+        const float S = __builtin_amdgcn_sqrtf(len2(ray.o)) * 1.000001f + __uint_as_float(run.tail().x);
         const float aSS = a * (S * S);
         tame = tame && aSS > 1e-20f && aSS < 1e37f;
     }
@@ -801,33 +827,36 @@ __device__ __forceinline__ void scan_tree(const SceneView &sc, const RunView &ru
         // start the run over in list order starts from it)
         float best_t = h.t;
         uint32_t best_slot = NO_SLOT;
+        // the run's primitives and their list positions, by slot
+        const RT_CONST_AS f4 *geom = KIND == DEV_SPHERE ? sc.sph_geom() : sc.tris();
+        const RT_CONST_AS uint32_t *by_slot = KIND == DEV_SPHERE ? sc.sph_id() : sc.tri_id();
         // primitives the tree does not hold (non-finite or huge coordinates): every ray tests them
-        const uint32_t n_unbounded = run.hi[10];
+        const uint32_t n_unbounded = run.tail().z;
         for (uint32_t k = 0; k < n_unbounded; ++k) {
-            const uint32_t slot = run.first + sc.order[run.order_base + run.count + k];
+            const uint32_t slot = run.first + sc.order()[run.order_base + run.count + k];
             if (walking && best_t == best_t) {
                 float t;
-                const bool closer = walk_test<KIND>(sc, slot, ray, aux, t_min, h.id, best_t, best_slot, t);
+                const bool closer = walk_test<KIND>(geom, by_slot, slot, ray, aux, t_min, h.id, best_t, best_slot, t);
                 best_t = closer ? t : best_t;
                 best_slot = closer ? slot : best_slot;
             }
         }
-        walk_tree<KIND>(sc, run, r, walking && best_t == best_t, tbl, tbl_run, tree_top, lds_from_level, ray, aux, t_min, h.id,
-                        best_t, best_slot);
+        walk_tree<KIND>(sc, run, r, walking && best_t == best_t, tbl, tbl_run, tree_top, lds_from_level, geom, by_slot,
+                        ray, aux, t_min, h.id, best_t, best_slot);
         if (walking && best_t != best_t) {
             listed = true;
         } else if (walking && best_slot != NO_SLOT) {
             h.t = best_t; h.kind = KIND; h.slot = best_slot;
-            h.id = (int32_t)(KIND == DEV_SPHERE ? sc.sph_id[best_slot] : sc.tri_id[best_slot]);
+            h.id = (int32_t)by_slot[best_slot];
             // temp_hr.front_face as the last accepted primitive of the run left it: the run's closest
-            if (sc.need_ff_shared)
+            if (sc.need_ff_shared())
                 ff_shared = (KIND == DEV_SPHERE ? sphere_front_face(sc, best_slot, ray, best_t, aux.cheap)
                                                 : tri_front_face(sc, best_slot, ray)) ? 1u : 0u;
         }
     }
     if (__builtin_amdgcn_ballot_w64(listed) != 0ull) {
         for (uint32_t k = 0; k < run.count; ++k) {
-            const uint32_t slot = run.first + sc.order[run.order_base + k];
+            const uint32_t slot = run.first + sc.order()[run.order_base + k];
             if (listed) {
                 if (KIND == DEV_SPHERE) sphere_exact(sc, slot, (int32_t)(run.id0 + k), ray, aux, t_min, h, ff_shared);
                 else tri_exact(sc, slot, (int32_t)(run.id0 + k), ray, t_min, h, ff_shared);
@@ -859,7 +888,8 @@ __device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, c
         const RunView run = load_run(sc, r);
         if (MODES != 0 && run.mode != RUN_EXACT) {
             // levels >= from are read from the LDS copy (only the cached run has any)
-            const uint32_t from = (r == sc.lds_run) ? sc.lds_level : 0xffffffffu;
+            const u4v in_lds = sc.lds();
+            const uint32_t from = (r == in_lds.x) ? in_lds.y : 0xffffffffu;
             if ((MODES & 1) && run.mode == RUN_FLAT) {
                 // the ball rejection test needs the unit direction and |o|^2
                 if (!have_cull) { cull = cull_setup(ray, a); have_cull = true; }
@@ -874,29 +904,32 @@ __device__ __forceinline__ void scan_list(const SceneView &sc, const Ray &ray, c
             // instructions (13 beside 20 vector ones for a sphere that is missed, at a quarter of the
             // rate) and the wait for the record are shared
             uint32_t k = 0;
+            const RT_CONST_AS f4 *geom = sc.sph_geom() + run.first;
             for (; k + 2u <= run.count; k += 2u) {
-                const f4 g0 = sc.sph_geom[run.first + k], g1 = sc.sph_geom[run.first + k + 1u];
+                const f4 g0 = geom[k], g1 = geom[k + 1u];
                 sphere_exact(sc, g0, run.first + k, (int32_t)(run.id0 + k), ray, aux, t_min, h, ff_shared);
                 sphere_exact(sc, g1, run.first + k + 1u, (int32_t)(run.id0 + k + 1u), ray, aux, t_min, h, ff_shared);
             }
             if (k < run.count)
-                sphere_exact(sc, run.first + k, (int32_t)(run.id0 + k), ray, aux, t_min, h, ff_shared);
+                sphere_exact(sc, geom[k], run.first + k, (int32_t)(run.id0 + k), ray, aux, t_min, h, ff_shared);
         } else if (run.kind == DEV_PLANE) {
             // Plane::hit, src/geometry/mod.rs:112-130
+            const RT_CONST_AS f4 *planes = sc.planes() + 2 * run.first;
             for (uint32_t k = 0; k < run.count; ++k) {
-                const f4 n4 = sc.planes[2 * (run.first + k)];
-                const f4 p4 = sc.planes[2 * (run.first + k) + 1];
+                const f4 n4 = planes[2 * k];
+                const f4 p4 = planes[2 * k + 1];
                 V3 n = mk(n4.x, n4.y, n4.z);
                 float t = dot(mk(p4.x, p4.y, p4.z) - ray.o, n) / dot(n, ray.d);
                 if (t < t_min || t > h.t) continue;
                 h.t = t; h.kind = DEV_PLANE; h.slot = run.first + k; h.id = (int32_t)(run.id0 + k);
-                if (sc.need_ff_shared) ff_shared = dot(ray.d, n) < 0.0f ? 1u : 0u;
+                if (sc.need_ff_shared()) ff_shared = dot(ray.d, n) < 0.0f ? 1u : 0u;
             }
         } else if (run.kind == DEV_CUBE) {
             // Cube::hit, src/geometry/mod.rs:158-223
+            const RT_CONST_AS f4 *cubes = sc.cubes() + 4 * run.first;
             for (uint32_t k = 0; k < run.count; ++k) {
-                const f4 c0 = sc.cubes[4 * (run.first + k) + 2];
-                const f4 c1 = sc.cubes[4 * (run.first + k) + 3];
+                const f4 c0 = cubes[4 * k + 2];
+                const f4 c1 = cubes[4 * k + 3];
                 float tmin, tmax, tymin, tymax, tzmin, tzmax;
                 if (ray.d.x >= 0.0f) { tmin = (c0.x - ray.o.x) / ray.d.x; tmax = (c1.x - ray.o.x) / ray.d.x; }
                 else                 { tmin = (c1.x - ray.o.x) / ray.d.x; tmax = (c0.x - ray.o.x) / ray.d.x; }
@@ -936,22 +969,23 @@ __device__ __forceinline__ uint32_t shade_hit(const SceneView &sc, const float *
     uint32_t mat;
     if (h.kind == DEV_SPHERE) {
         // src/geometry/mod.rs:81-86
-        const f4 g = sc.sph_geom[h.slot];
+        const f4 g = sc.sph_geom()[h.slot];
         V3 outward = div3(p - mk(g.x, g.y, g.z), g.w, cheap);   // |p - c| < 2^60 by the bounds `cheap` stands for
         ff = dot(ray.d, outward) < 0.0f;
         normal = ff ? outward : -outward;
-        mat = sc.sph_mat[h.slot];
+        mat = sc.sph_mat()[h.slot];
     } else if (h.kind == DEV_PLANE) {
         // src/geometry/mod.rs:120-123
-        const f4 n4 = sc.planes[2 * h.slot];
+        const f4 n4 = sc.planes()[2 * h.slot];
         V3 outward = mk(n4.x, n4.y, n4.z);
         ff = dot(ray.d, outward) < 0.0f;
         normal = ff ? outward : -outward;
         mat = __float_as_uint(n4.w);
     } else if (h.kind == DEV_CUBE) {
         // src/geometry/mod.rs:208-216
-        const f4 cc = sc.cubes[4 * h.slot];
-        const f4 hw = sc.cubes[4 * h.slot + 1];   // w/2, h/2, d/2
+        const RT_CONST_AS f4 *cube = sc.cubes() + 4 * h.slot;
+        const f4 cc = cube[0];
+        const f4 hw = cube[1];   // w/2, h/2, d/2
         const float eps = 1.0001f;
         V3 pc = p - mk(cc.x, cc.y, cc.z);
         V3 nn;
@@ -961,16 +995,18 @@ __device__ __forceinline__ uint32_t shade_hit(const SceneView &sc, const float *
         normal = unit(nn);
         mat = __float_as_uint(cc.w);
     } else {
-        const f4 v0 = sc.tris[3 * h.slot];
-        const f4 e1 = sc.tris[3 * h.slot + 1];
-        const f4 e2 = sc.tris[3 * h.slot + 2];
+        const RT_CONST_AS f4 *tri = sc.tris() + 3 * h.slot;
+        const f4 v0 = tri[0];
+        const f4 e1 = tri[1];
+        const f4 e2 = tri[2];
         V3 outward = unit(cross(mk(e1.x, e1.y, e1.z), mk(e2.x, e2.y, e2.z)));
         ff = dot(ray.d, outward) < 0.0f;
         normal = ff ? outward : -outward;
         mat = __float_as_uint(v0.w);
     }
-    const f4 ma = sc.mat_rec[2u * mat];        // r, g, b, param
-    const f4 mb = sc.mat_rec[2u * mat + 1u];   // kind, 1/param, r0 for a front face, r0 for a back face
+    const RT_CONST_AS f4 *material = sc.mat_rec() + 2u * mat;
+    const f4 ma = material[0];   // r, g, b, param
+    const f4 mb = material[1];   // kind, 1/param, r0 for a front face, r0 for a back face
     const int mk_ = (int)__float_as_uint(mb.x);
     V3 dir;
     // `ud` is unit_vector(r_in.direction) (src/geometry/mod.rs:276,326), the same value for
@@ -1299,7 +1335,7 @@ void render_tiles(KernArgs by_value) {
         const unsigned long long tm0 = __builtin_readcyclecounter();
 #endif
         const RT_CONST_AS KernArgs *k = args();
-        const SceneView sc = view_of(k->dsc, k->fr.segments);
+        const SceneView sc = view_of(&k->dsc, k->fr.segments, MODES != 0);
         const float t_min = k->p.t_min;
         // |direction|^2 and whether the short division and root sequences apply (see RayAux)
         const bool cheap_frame = RTK_SHORT_ARITH && k->dsc.cheap_ok != 0u && t_min >= 0x1p-20f;
@@ -1321,7 +1357,7 @@ void render_tiles(KernArgs by_value) {
         if (alive) {
             // (the arguments the shading needs are read after the scan, not kept across it)
             const RT_CONST_AS KernArgs *ks = args();
-            const SceneView sc = view_of(ks->dsc, ks->fr.segments);
+            const SceneView sc = view_of(&ks->dsc, ks->fr.segments, MODES != 0);
             const uint32_t n_stack = max_bounces - depth_left;   // hits of this path so far
             if (n_stack == 0u) {
                 const Where at = where(item);
