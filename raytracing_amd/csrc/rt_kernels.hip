@@ -59,18 +59,16 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) {
 __device__ __forceinline__ V3 unit(V3 a) { return a / __builtin_sqrtf(len2(a)); }
 // src/vector/mod.rs:91-93
 __device__ __forceinline__ V3 reflect(V3 v, V3 n) { return v - (n * 2.0f) * dot(v, n); }
-// Rust f32::min
-__device__ __forceinline__ float rmin(float a, float b) {
-    if (a != a) return b;
-    if (b != b) return a;
-    return a < b ? a : b;
-}
-// Rust `as i32`
+// Rust f32::min (a NaN operand gives the other one): v_min_f32 in the IEEE mode kernels run in.
+// Its callers pass a constant as b, so the order of -0 and +0, which neither defines, never matters.
+__device__ __forceinline__ float rmin(float a, float b) { return __builtin_fminf(a, b); }
+// Rust `as i32` and back: truncation towards zero, NaN -> 0, values beyond the range saturate
+// ((i32::MAX as f32) rounds to 2^31).  v_cvt_i32_f32 is defined to do exactly that; written as the
+// instruction because a C++ cast of such a value has no defined result.
 __device__ __forceinline__ float trunc_i32_as_f32(float x) {
-    if (x != x) return 0.0f;
-    if (x >= 2147483648.0f) return 2147483648.0f;   // (i32::MAX as f32) rounds to 2^31
-    if (x <= -2147483648.0f) return -2147483648.0f;
-    return (float)(int32_t)x;
+    int32_t i;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(i) : "v"(x));
+    return (float)i;
 }
 
 // ------------------------------------------------------------------ quotients and roots
@@ -992,7 +990,10 @@ __device__ __forceinline__ uint32_t shade_hit(const SceneView &sc, const float *
         nn.x = trunc_i32_as_f32(eps * pc.x / hw.x);
         nn.y = trunc_i32_as_f32(eps * pc.y / hw.y);
         nn.z = trunc_i32_as_f32(eps * pc.z / hw.z);
-        normal = unit(nn);
+        // unit_vector(nn): a hit on a face (not within 1e-4 of an edge) has one component of +-1 and two
+        // zeros (+0: they come from integers): length 1, and x / 1 = x
+        if (__builtin_amdgcn_ballot_w64(len2(nn) != 1.0f) == 0ull) normal = nn;
+        else normal = unit(nn);
         mat = __float_as_uint(cc.w);
     } else {
         const RT_CONST_AS f4 *tri = sc.tris() + 3 * h.slot;
