@@ -320,6 +320,30 @@ def test_degenerate_rays_and_nans(renderer, oracle, tables):
         renderer.set_tables(tables)
 
 
+@pytest.mark.parametrize("thin", [0.0, 1e-30, 1e-20, 1e-9])
+def test_plates_whose_normal_saturates_the_integer_conversion(renderer, oracle, tables, thin):
+    """Cube::hit's normal is `(1.0001 * (p - c) / half_width) as i32` per axis (src/geometry/mod.rs:211-215).
+    On a plate of (next to) no thickness the quotient is far beyond the i32 range, infinite, or 0/0:
+    Rust's cast saturates and turns NaN into 0."""
+    s = HittableList()
+    s.add(Cube((0.0, 0.0, -3.0), thin, 2.0, 2.0, Lambertian((0.8, 0.3, 0.3))))
+    s.add(Cube((-1.5, 0.5, -2.0), 1.5, thin, 1.5, Metal((0.8, 0.8, 0.8), 0.1)))
+    s.add(Cube((1.5, 0.0, -2.5), 1.0, 1.0, thin, Dielectric((0.9, 0.9, 1.0), 1.5)))
+    s.add(Cube((0.5, -0.5, -1.5), thin, thin, 1.0, Lambertian((0.2, 0.8, 0.2))))
+    s.add(Plane((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), Lambertian((0.5, 0.5, 0.5))))
+    cam = Camera.new(60.0, 1.5, 0.0, 1.0, (0.7, 0.4, 1.0), (0.0, 0.0, -2.5), (0.0, 1.0, 0.0))
+    p = make_params(96, 64, spp=4)
+    gpu = render_gpu(renderer, s.flatten(), cam, [p])
+    orc = render_oracle(oracle, tables, s.flatten(), cam, [p])
+    a, b = gpu[0], orc[0][..., :3]
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    ok = ~np.isnan(a)
+    assert np.array_equal(_bits(a)[ok], _bits(b)[ok])
+    assert np.array_equal(gpu[1], orc[1]) and gpu[3] == orc[2]
+    assert np.array_equal(gpu[2], oracle.pack(orc[0]))
+    assert (gpu[1] >= 0).sum() > 500 and set(np.unique(gpu[1])) >= {0, 1, 2}     # the plates are in the picture
+
+
 def test_many_spheres_small_frame(renderer, oracle, tables):
     """configs[3]'s scene (10,000 spheres + plane) on a frame the oracle can finish"""
     wl = workloads.workload("c4")
