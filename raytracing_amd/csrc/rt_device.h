@@ -23,7 +23,7 @@ enum { RUN_EXACT = 0, RUN_FLAT = 1, RUN_TREE = 2 };
 // Vec<Box<dyn Hittable>> (src/geometry/mod.rs:228-238).  128 bytes, read with two
 // scalar loads.  A RUN_FLAT run has its rejection records in DevScene::cull_rec (steps of
 // eight records, 128 bytes).  A RUN_TREE run has an implicit 8-ary tree of boxes in
-// DevScene::tree_rec: level 0 holds one box per primitive in steps of eight (12 float4),
+// DevScene::tree_rec: level 0 holds one box per primitive in steps of eight (DEV_NODE_F4 float4),
 // level L+1 one bounding box per step of level L, again in steps of eight; the children of
 // step s of level L+1 are steps 8s..8s+7 of level L.
 struct DevRun {
@@ -60,8 +60,8 @@ struct DevScene {
     const uint32_t *tri_id;   // list position                       (by slot)
     const float4 *cull_rec;   // RUN_FLAT rejection records, 8 float4 per step of eight balls:
                               // four pairs {cx0,cx1, cy0,cy1}{cz0,cz1, thr0,thr1}
-    const float4 *tree_rec;   // RUN_TREE records, 12 float4 per step of eight boxes:
-                              // per pair of boxes {lo0,lo1,hi0,hi1} for x, y, z
+    const float4 *tree_rec;   // RUN_TREE records, DEV_NODE_F4 float4 per step of eight boxes (72 floats):
+                              // per pair of boxes {lo0,lo1,hi0,hi1,lo0,lo1} for x, y, z
     const uint32_t *order;    // see DevRun::order_base
     const float4 *mat_rec;    // 2 per material: {r, g, b, param}, {kind bits, 1/param, r0 front, r0 back}
                               // (Dielectric: ratio and reflectance at normal incidence for either face,
@@ -69,6 +69,8 @@ struct DevScene {
     // the top levels of ONE tree run are copied into LDS by every workgroup:
     // levels >= lds_level of run lds_run, tree_rec float4s [lds_first, +lds_count)
     uint32_t lds_run, lds_level, lds_first, lds_count;
+    // the same for a launch with the deep material stack (less room): the launch copies them over the four above
+    uint32_t lds_deep_level, lds_deep_first, lds_deep_count;
     uint32_t modes;           // bit 0: some run is RUN_FLAT, bit 1: some run is RUN_TREE
     uint32_t cheap_ok;        // every sphere has finite |centre| <= 2^30 and 2^-30 <= |radius| <= 2^30: rays of
                               // moderate origin and length may take the short division and root sequences
@@ -81,8 +83,24 @@ struct DevScene {
 #define DEV_STAGE_SLOTS 4u
 struct StagedRgb { float r, g, b; };
 #define DEV_STAGE_WAVE_BYTES ((size_t)sizeof(StagedRgb) * DEV_STAGE_SLOTS << DEV_STAGE_ITEM_BITS)   // 24 KiB
+// float4s per step of eight boxes in tree_rec.  18 (DEV_NODE_MIRROR, the default): per pair of boxes
+// and axis {lo0,lo1,hi0,hi1,lo0,lo1}, of which a lane reads the first or the last four by the sign
+// of its ray's direction: near planes first, far planes second, without a comparison.
+// 12 (DEV_NODE_MIRROR=0, for comparison): {lo0,lo1,hi0,hi1}, near and far sorted out by the test.
+#ifndef DEV_NODE_MIRROR
+#define DEV_NODE_MIRROR 1
+#endif
+#define DEV_NODE_F4 (DEV_NODE_MIRROR ? 18u : 12u)
+// The render kernel of a scene with a tree exists for two depth budgets: up to DEV_STACK_SHALLOW
+// bounces (the reference's 10, src/raytracer.rs:132) and up to RT_MAX_BOUNCES.  The material stack
+// in LDS is sized by it, and what it leaves of a workgroup's 80 KB goes to the copy of a tree's
+// top levels: DEV_TREE_LDS_F4 / DEV_TREE_LDS_F4_DEEP float4s.
+#define DEV_STACK_SHALLOW 10u
 #ifndef DEV_TREE_LDS_F4
-#define DEV_TREE_LDS_F4 2256u     // float4s of tree per workgroup (35 KB): the workgroup's LDS stays under 80 KB
+#define DEV_TREE_LDS_F4 (DEV_NODE_MIRROR ? 3528u : 2352u)        // 56 KB
+#endif
+#ifndef DEV_TREE_LDS_F4_DEEP
+#define DEV_TREE_LDS_F4_DEEP (DEV_NODE_MIRROR ? 2754u : 2748u)   // 44 KB
 #endif
 
 // Per-frame buffers and the lookup tables

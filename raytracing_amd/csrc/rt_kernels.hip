@@ -138,6 +138,7 @@ constexpr uint32_t GOLDEN32 = 0x9E3779B9u;
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16 __attribute__((ext_vector_type(16)));
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef f4 f4a8 __attribute__((aligned(8)));   // four floats at an address that is a multiple of eight
 typedef uint32_t u16v __attribute__((ext_vector_type(16)));
 typedef uint32_t u8v __attribute__((ext_vector_type(8)));
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
@@ -170,7 +171,7 @@ struct SceneView {
     __device__ __forceinline__ const RT_CONST_AS f4 *tris() const { return const_ptr<f4>(at()->tris); }
     __device__ __forceinline__ const RT_CONST_AS f4 *mat_rec() const { return const_ptr<f4>(at()->mat_rec); }
     __device__ __forceinline__ const RT_CONST_AS f16 *cull_rec() const { return const_ptr<f16>(at()->cull_rec); }   // RUN_FLAT: two per step of eight records
-    __device__ __forceinline__ const RT_CONST_AS f4 *tree_rec() const { return const_ptr<f4>(at()->tree_rec); }     // RUN_TREE: twelve per step of eight boxes
+    __device__ __forceinline__ const RT_CONST_AS f4 *tree_rec() const { return const_ptr<f4>(at()->tree_rec); }     // RUN_TREE: DEV_NODE_F4 per step of eight boxes
     __device__ __forceinline__ const RT_CONST_AS uint32_t *sph_mat() const { return const_ptr<uint32_t>(at()->sph_mat); }
     __device__ __forceinline__ const RT_CONST_AS uint32_t *sph_id() const { return const_ptr<uint32_t>(at()->sph_id); }
     __device__ __forceinline__ const RT_CONST_AS uint32_t *tri_id() const { return const_ptr<uint32_t>(at()->tri_id); }
@@ -249,18 +250,19 @@ struct UnitRing { uint32_t xy[4], left[4]; };
 // MODES: bit 0 = the scene has RUN_FLAT runs, bit 1 = it has RUN_TREE runs; the
 // kernel is compiled once per combination so that scenes without a tree do not
 // pay registers and LDS for it
-template <int MODES>
+// DEPTH: the largest depth budget the kernel takes (DEV_STACK_SHALLOW or RT_MAX_BOUNCES; with a tree
+// the shallow kernel has room for more of it in LDS)
+template <int MODES, int DEPTH>
 struct Lds {
+    // top levels of one tree (DevScene::lds_*); first, so that reads of two 8-byte halves reach a
+    // whole node with their 8-bit offsets
+    f4 tree_top[(MODES & 2) ? (DEPTH > (int)DEV_STACK_SHALLOW ? DEV_TREE_LDS_F4_DEEP : DEV_TREE_LDS_F4) : 1];
     float disc[128];                                    // src/denoising/mod.rs:55
     float sphere[768];                                  // src/denoising/mod.rs:59
-#ifndef RTK_STACK_DEPTH
-#define RTK_STACK_DEPTH RT_MAX_BOUNCES
-#endif
-    uint32_t mat_stack[waves_of(MODES)][RTK_STACK_DEPTH][64];
+    uint32_t mat_stack[waves_of(MODES)][DEPTH][64];     // materials of the path's hits so far, per lane
     TreeTable tree[waves_of(MODES)];                    // per-level constants of the run being walked
     UnitRing ring[waves_of(MODES)];                     // the units each wave has in flight
     float uv[4];                                        // width - 1, height - 1, their refined reciprocals
-    f4 tree_top[(MODES & 2) ? DEV_TREE_LDS_F4 : 1];     // top levels of one tree (DevScene::lds_*)
 };
 
 struct Ray { V3 o, d; };
@@ -602,7 +604,7 @@ __device__ __forceinline__ void scan_flat(const SceneView &sc, const RunView &ru
 // lane walks the tree for its own ray.  No stack: the path is the step index itself
 // (parent = s >> 3), the children still to visit are one byte per level in a 64-bit register.
 //
-// Per trip a lane fetches ITS node (192 bytes), tests the eight child boxes and descends into
+// Per trip a lane fetches ITS node, tests the eight child boxes and descends into
 // the survivor the ray enters first; on level 0 the survivors get the exact test instead.
 // When no child survives, or after a leaf step, the lane moves on to its next pending node;
 // the walk ends when a ballot says no lane has a node left.
@@ -620,6 +622,11 @@ __device__ __forceinline__ void scan_flat(const SceneView &sc, const RunView &ru
 //       to is off by < 4 ulp S;
 //   (b) each t is off by a few ulp of (|plane| + |o| + pad) |1/d|, i.e. the plane by a few
 //       ulp of S.  2^-17 S covers (b) and the triangles' (a) three times over.
+// A node stores, per pair of child boxes and axis, {lo0, lo1, hi0, hi1, lo0, lo1}: a lane reads
+// four of the six, from the first if its ray runs up that axis and from the third if it runs
+// down, and so gets the planes it reaches first in the first two and the planes it leaves
+// through in the last two without comparing anything (192 of the node's 288 bytes; the entry
+// distance is then one v_max3 and one v_max, the exit distance one v_min3 and one v_min).
 // A lane leaves the walk as soon as its closest_so_far turns NaN (see scan_tree).
 // ----------------------------------------------------------------------
 // The walk keeps the closest hit so far as a distance and a slot of the run (NO_SLOT: still
@@ -672,6 +679,12 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
     const float iz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(ray.d.z), -1e19f, 1e19f);
     const float klx = -((ray.o.x + pad) * ix), kly = -((ray.o.y + pad) * iy), klz = -((ray.o.z + pad) * iz);
     const float khx = -((ray.o.x - pad) * ix), khy = -((ray.o.y - pad) * iy), khz = -((ray.o.z - pad) * iz);
+#if DEV_NODE_MIRROR
+    const uint32_t offx = ix < 0.0f ? 2u : 0u, offy = iy < 0.0f ? 2u : 0u, offz = iz < 0.0f ? 2u : 0u;
+    const float knx = ix < 0.0f ? khx : klx, kfx = ix < 0.0f ? klx : khx;
+    const float kny = iy < 0.0f ? khy : kly, kfy = iy < 0.0f ? kly : khy;
+    const float knz = iz < 0.0f ? khz : klz, kfz = iz < 0.0f ? klz : khz;
+#endif
     const uint32_t top = run.n_levels - 1u;
     const RT_CONST_AS f4 *nodes = sc.tree_rec();
     const uint32_t lds_first = sc.lds().z;
@@ -695,6 +708,54 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
         while (act) {
             {
 #endif
+#if DEV_NODE_MIRROR
+                // the node's records as floats; a lane reads four from each, starting at the first
+                // (near planes = low planes) or the third (near planes = high planes)
+                const uint32_t at = 4u * tbl.base[L] + 72u * st;
+                f4 nd[12];
+                if (L >= lds_from_level) {
+                    const float *src = (const float *)tree_top + (at - 4u * lds_first);
+                    const float *sx = src + offx, *sy = src + offy, *sz = src + offz;
+#pragma unroll
+                    for (int pr = 0; pr < 4; ++pr) {
+                        nd[3 * pr] = *(const f4a8 *)(sx + 18 * pr);
+                        nd[3 * pr + 1] = *(const f4a8 *)(sy + 18 * pr + 6);
+                        nd[3 * pr + 2] = *(const f4a8 *)(sz + 18 * pr + 12);
+                    }
+                } else {
+                    const RT_CONST_AS float *src = (const RT_CONST_AS float *)nodes + (size_t)at;
+                    const RT_CONST_AS float *sx = src + offx, *sy = src + offy, *sz = src + offz;
+#pragma unroll
+                    for (int pr = 0; pr < 4; ++pr) {
+                        nd[3 * pr] = *(const RT_CONST_AS f4a8 *)(sx + 18 * pr);
+                        nd[3 * pr + 1] = *(const RT_CONST_AS f4a8 *)(sy + 18 * pr + 6);
+                        nd[3 * pr + 2] = *(const RT_CONST_AS f4a8 *)(sz + 18 * pr + 12);
+                    }
+                }
+                uint32_t live = 0u;               // children the ray may hit
+                uint32_t nearest = 0xffffffffu;   // min over them of (entry distance | index)
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    const f4 X = nd[3 * pr], Y = nd[3 * pr + 1], Z = nd[3 * pr + 2];   // near0, near1, far0, far1
+                    const f2 ix2 = {ix, ix}, iy2 = {iy, iy}, iz2 = {iz, iz};
+                    const f2 tnx = __builtin_elementwise_fma(X.xy, ix2, (f2){knx, knx}), tfx = __builtin_elementwise_fma(X.zw, ix2, (f2){kfx, kfx});
+                    const f2 tny = __builtin_elementwise_fma(Y.xy, iy2, (f2){kny, kny}), tfy = __builtin_elementwise_fma(Y.zw, iy2, (f2){kfy, kfy});
+                    const f2 tnz = __builtin_elementwise_fma(Z.xy, iz2, (f2){knz, knz}), tfz = __builtin_elementwise_fma(Z.zw, iz2, (f2){kfz, kfz});
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        // [enter, leave] = [t_low, closest_so_far] cut down by the three slabs
+                        float enter = __builtin_fmaxf(__builtin_fmaxf(c ? tnx.y : tnx.x, c ? tny.y : tny.x), c ? tnz.y : tnz.x);
+                        float leave = __builtin_fminf(__builtin_fminf(c ? tfx.y : tfx.x, c ? tfy.y : tfy.x), c ? tfz.y : tfz.x);
+                        enter = __builtin_fmaxf(enter, t_low);
+                        leave = __builtin_fminf(leave, best_t);
+                        const uint32_t m = (uint32_t)((int32_t)__float_as_uint(enter - leave) >> 31);
+                        const uint32_t child = (uint32_t)(2 * pr + c);
+                        live |= m & (1u << child);
+                        const uint32_t key = (__float_as_uint(enter) & ~7u) | child;
+                        nearest = min(nearest, (key & m) | ~m);
+                    }
+                }
+#else
                 const uint32_t at = tbl.base[L] + 12u * st;
                 f4 nd[12];
                 if (L >= lds_from_level) {
@@ -741,6 +802,7 @@ __device__ __forceinline__ void walk_tree(const SceneView &sc, const RunView &ru
                         nearest = min(nearest, (key & m) | ~m);
                     }
                 }
+#endif
                 // children past the end of the level below do not exist
                 const uint32_t have = min(8u, tbl.count[L] - 8u * st);
                 uint32_t bits = live & ((1u << have) - 1u);
@@ -1094,7 +1156,7 @@ constexpr uint32_t ITEM_BITS = DEV_STAGE_ITEM_BITS;   // item index inside a uni
 // the arguments of render_tiles as they lie in the kernel's argument block
 struct KernArgs { DevScene dsc; rt_camera cam; rt_params p; DevFrame fr; uint32_t n_bands, unit_px_log2, stretch_unit; };
 
-template <int MODES>
+template <int MODES, int DEPTH>
 // Two 8-wave workgroups per CU: four waves per SIMD, at most 128 VGPRs each (some per-item
 // state is spilled around the walk).  Measured alternatives on the 10,000-sphere frame: three
 // waves per SIMD without spills (one 12-wave workgroup per CU) -14 %, 4-wave workgroups with
@@ -1102,7 +1164,7 @@ template <int MODES>
 // 6- or 10-wave workgroups fit only once per CU.
 __global__ __launch_bounds__(waves_of(MODES) * 64, occ_hint_of(MODES))
 void render_tiles(KernArgs by_value) {
-    __shared__ Lds<MODES> lds;
+    __shared__ Lds<MODES, DEPTH> lds;
 #ifdef RTK_WAVE_ENDS
     const unsigned long long t_begin = wall_clock64();
 #endif
@@ -1599,21 +1661,37 @@ hipError_t rtk_launch_pack_bands(const float4 *accum, uint32_t *out, uint32_t W,
                        n_bands);
     return hipGetLastError();
 }
-// workgroups of render_tiles<modes> that fit one CU, asked once per process (the same on every GPU of a node)
-static uint32_t blocks_per_cu(uint32_t modes) {
+// The instantiations: scenes without a tree have one kernel for every depth budget, scenes with
+// one a kernel for up to DEV_STACK_SHALLOW bounces and one for more (index: modes, + 4 for the latter).
+static const void *render_kernel(uint32_t which) {
+    switch (which) {
+    case 0: return (const void *)rtk::render_tiles<0, RT_MAX_BOUNCES>;
+    case 1: return (const void *)rtk::render_tiles<1, RT_MAX_BOUNCES>;
+    case 2: return (const void *)rtk::render_tiles<2, DEV_STACK_SHALLOW>;
+    case 3: return (const void *)rtk::render_tiles<3, DEV_STACK_SHALLOW>;
+    case 6: return (const void *)rtk::render_tiles<2, RT_MAX_BOUNCES>;
+    case 7: return (const void *)rtk::render_tiles<3, RT_MAX_BOUNCES>;
+    default: return nullptr;
+    }
+}
+static uint32_t kernel_index(uint32_t modes, uint32_t max_bounces) {
+    return (modes & 3u) + (((modes & 2u) && max_bounces > DEV_STACK_SHALLOW) ? 4u : 0u);
+}
+// workgroups of a render kernel that fit one CU, asked once per process (the same on every GPU of a node)
+static uint32_t blocks_per_cu(uint32_t which) {
     static std::once_flag once;
-    static int fit[4] = {0, 0, 0, 0};
+    static int fit[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::call_once(once, [] {
-        const void *kernels[4] = {(const void *)rtk::render_tiles<0>, (const void *)rtk::render_tiles<1>,
-                                  (const void *)rtk::render_tiles<2>, (const void *)rtk::render_tiles<3>};
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < 8; ++m) {
+            const void *kernel = render_kernel((uint32_t)m);
+            if (!kernel) continue;
             int n = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernels[m], rtk::waves_of(m) * 64, 0) != hipSuccess || n <= 0)
-                n = 4 * rtk::occ_hint_of(m) / rtk::waves_of(m);      // what the compiler was told
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, rtk::waves_of(m & 3) * 64, 0) != hipSuccess || n <= 0)
+                n = 4 * rtk::occ_hint_of(m & 3) / rtk::waves_of(m & 3);      // what the compiler was told
             fit[m] = n;
         }
     });
-    return (uint32_t)fit[modes & 3u];
+    return (uint32_t)fit[which & 7u];
 }
 uint32_t rtk_resident_waves(uint32_t n_cus) {
     (void)blocks_per_cu(0u);   // asked here, when a context is made, so that no launch has to
@@ -1628,7 +1706,7 @@ hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_
     // workgroups the chip holds at once (what the kernel is written for, and no more than the runtime
     // says fit a CU: a workgroup that is not resident would start its first unit when another one ends),
     // and the staging ring has room for
-    const uint64_t resident = std::min<uint64_t>((uint64_t)n_cus * std::min<uint32_t>(4u * rtk::occ_of((int)(sc.modes & 3u)) / waves, blocks_per_cu(sc.modes & 3u)),
+    const uint64_t resident = std::min<uint64_t>((uint64_t)n_cus * std::min<uint32_t>(4u * rtk::occ_of((int)(sc.modes & 3u)) / waves, blocks_per_cu(kernel_index(sc.modes, p.max_bounces))),
                                                  stage_waves / waves);
     if (p.sample_count > DEV_SAMPLE_CHUNK || p.width > 65536u || p.height > 65536u || resident == 0u) return hipErrorInvalidValue;
     const uint64_t max_items = 1ull << DEV_STAGE_ITEM_BITS;    // a unit's colours must fit one ring slot
@@ -1663,12 +1741,21 @@ hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_
     // used only while much is left, and only by the kernels with a tree: 10,000 spheres 4K -0.4 %, a
     // million triangles -1 %.
     const uint64_t stretch_unit = std::min<uint64_t>(32u * groups * waves, 0x1fffffffu);
-    const rtk::KernArgs ka{sc, cam, p, fr, n_bands, r, (uint32_t)stretch_unit};
-    switch (sc.modes & 3u) {
-    case 0: hipLaunchKernelGGL(rtk::render_tiles<0>, grid, block, 0, stream, ka); break;
-    case 1: hipLaunchKernelGGL(rtk::render_tiles<1>, grid, block, 0, stream, ka); break;
-    case 2: hipLaunchKernelGGL(rtk::render_tiles<2>, grid, block, 0, stream, ka); break;
-    default: hipLaunchKernelGGL(rtk::render_tiles<3>, grid, block, 0, stream, ka); break;
+    rtk::KernArgs ka{sc, cam, p, fr, n_bands, r, (uint32_t)stretch_unit};
+    if (p.max_bounces > RT_MAX_BOUNCES) return hipErrorInvalidValue;
+    const uint32_t which = kernel_index(sc.modes, p.max_bounces);
+    if (which >= 4u) {
+        // the deep material stack leaves less room for the tree's top levels
+        ka.dsc.lds_level = sc.lds_deep_level; ka.dsc.lds_first = sc.lds_deep_first; ka.dsc.lds_count = sc.lds_deep_count;
+        if (sc.lds_deep_level == 0xffffffffu) ka.dsc.lds_run = 0xffffffffu;
+    }
+    switch (which) {
+    case 0: hipLaunchKernelGGL((rtk::render_tiles<0, RT_MAX_BOUNCES>), grid, block, 0, stream, ka); break;
+    case 1: hipLaunchKernelGGL((rtk::render_tiles<1, RT_MAX_BOUNCES>), grid, block, 0, stream, ka); break;
+    case 2: hipLaunchKernelGGL((rtk::render_tiles<2, DEV_STACK_SHALLOW>), grid, block, 0, stream, ka); break;
+    case 3: hipLaunchKernelGGL((rtk::render_tiles<3, DEV_STACK_SHALLOW>), grid, block, 0, stream, ka); break;
+    case 6: hipLaunchKernelGGL((rtk::render_tiles<2, RT_MAX_BOUNCES>), grid, block, 0, stream, ka); break;
+    default: hipLaunchKernelGGL((rtk::render_tiles<3, RT_MAX_BOUNCES>), grid, block, 0, stream, ka); break;
     }
     return hipGetLastError();
 }

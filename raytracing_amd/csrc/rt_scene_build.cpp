@@ -167,8 +167,9 @@ void append_paired(std::vector<float4> &out, const std::vector<float4> &recs) {
     }
 }
 
-// Appends one level of boxes (one per entry of `boxes`, in steps of eight, twelve float4
-// per step: per pair of boxes {lo0,lo1,hi0,hi1} for x, for y, for z), rounded outwards.
+// Appends one level of boxes (one per entry of `boxes`, in steps of eight, DEV_NODE_F4 float4
+// per step: per pair of boxes {lo0,lo1,hi0,hi1,lo0,lo1} for x, for y, for z - a ray reads the first
+// four or the last four, whichever has its near planes first), rounded outwards.
 void append_box_level(std::vector<float4> &out, const std::vector<Box> &boxes) {
     const size_t m = boxes.size(), n_steps = (m + 7) / 8;
     for (size_t st = 0; st < n_steps; ++st) {
@@ -183,16 +184,27 @@ void append_box_level(std::vector<float4> &out, const std::vector<Box> &boxes) {
                 lo[c][ax] = empty ? 3.0e38f : round_down(boxes[8 * st + c].lo[ax]);
                 hi[c][ax] = empty ? 3.0e38f : round_up(boxes[8 * st + c].hi[ax]);
             }
+#if DEV_NODE_MIRROR
+        float rec[72];
+        for (int pr = 0; pr < 4; ++pr)
+            for (int ax = 0; ax < 3; ++ax) {
+                float *r = rec + 6 * (3 * pr + ax);
+                r[0] = lo[2 * pr][ax]; r[1] = lo[2 * pr + 1][ax]; r[2] = hi[2 * pr][ax]; r[3] = hi[2 * pr + 1][ax];
+                r[4] = r[0]; r[5] = r[1];
+            }
+        for (int q = 0; q < 18; ++q) out.push_back(make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]));
+#else
         for (int pr = 0; pr < 4; ++pr)
             for (int ax = 0; ax < 3; ++ax)
                 out.push_back(make_float4(lo[2 * pr][ax], lo[2 * pr + 1][ax], hi[2 * pr][ax], hi[2 * pr + 1][ax]));
+#endif
     }
 }
 
 // Builds the implicit 8-ary tree over the leaves of a run (already in slot order) and
 // appends its records to scene.tree_rec.
 //   level 0   one box per primitive (a sphere's extent, a triangle's gate box), in steps of
-//             eight, twelve float4 per step;
+//             eight, DEV_NODE_F4 float4 per step;
 //   level L>0 one box per step of level L-1, in steps of eight.
 // Boxes hold plain extents rounded outwards; the kernel widens them per ray by a pad that
 // covers what the reference's f32 arithmetic can add to a primitive's reach (for a sphere:
@@ -434,13 +446,23 @@ int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::strin
         if (run.count <= best) continue;
         best = run.count;
         const uint32_t top = run.n_levels - 1u;
-        const uint32_t end = run.level_base[top] + run.top_steps * 12u;   // top >= 1: a box level
-        uint32_t L = top;
-        while (L > 0 && end - run.level_base[L - 1] <= DEV_TREE_LDS_F4) --L;
-        if (end - run.level_base[L] > DEV_TREE_LDS_F4) continue;   // even the top level alone is too big
+        const uint32_t end = run.level_base[top] + run.top_steps * DEV_NODE_F4;   // top >= 1: a box level
+        auto levels_that_fit = [&](uint32_t room) {
+            uint32_t L = top;
+            while (L > 0 && end - run.level_base[L - 1] <= room) --L;
+            return end - run.level_base[L] > room ? 0xffffffffu : L;   // even the top level alone may be too big
+        };
+        const uint32_t L = levels_that_fit(DEV_TREE_LDS_F4), Ld = levels_that_fit(DEV_TREE_LDS_F4_DEEP);
+        if (L == 0xffffffffu) continue;
         sc.lds_run = r; sc.lds_level = L;
         sc.lds_first = run.level_base[L];
         sc.lds_count = end - run.level_base[L];
+        sc.lds_deep_level = 0xffffffffu; sc.lds_deep_first = 0; sc.lds_deep_count = 0;
+        if (Ld != 0xffffffffu) {
+            sc.lds_deep_level = Ld;
+            sc.lds_deep_first = run.level_base[Ld];
+            sc.lds_deep_count = end - run.level_base[Ld];
+        }
     }
     return RT_OK;
 }

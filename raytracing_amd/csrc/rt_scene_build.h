@@ -14,12 +14,13 @@ struct HostScene {
     std::vector<float4> planes, cubes, tris;
     std::vector<uint32_t> tri_id;
     std::vector<float4> cull_rec;     // RUN_FLAT rejection records, 8 float4 per step
-    std::vector<float4> tree_rec;     // RUN_TREE records, 10 float4 per step
+    std::vector<float4> tree_rec;     // RUN_TREE records, DEV_NODE_F4 float4 per step
     std::vector<uint32_t> order;      // per tree/flat run: list position -> slot offset
     std::vector<float4> mat_rec;      // 2 per material, see DevScene::mat_rec
     uint32_t need_ff_shared = 0;
     uint32_t cheap_ok = 1;            // see DevScene::cheap_ok
     uint32_t lds_run = 0xffffffffu, lds_level = 0, lds_first = 0, lds_count = 0;
+    uint32_t lds_deep_level = 0xffffffffu, lds_deep_first = 0, lds_deep_count = 0;   // see DevScene
     uint32_t modes = 0;
 };
 

@@ -350,6 +350,16 @@ def test_many_spheres_small_frame(renderer, oracle, tables):
     check(renderer, oracle, tables, wl["flat"], wl["camera"], [make_params(96, 54, spp=2)])
 
 
+@pytest.mark.parametrize("max_bounces", [10, 11, 16])
+def test_tree_scenes_on_both_sides_of_the_shallow_depth_budget(renderer, oracle, tables, max_bounces):
+    """scenes with a box tree have one kernel for up to 10 bounces (the reference's budget,
+    src/raytracer.rs:132) and one for up to 16, with less of the tree in LDS"""
+    wl = workloads.workload("c4")
+    check(renderer, oracle, tables, wl["flat"], wl["camera"], [make_params(96, 54, spp=2, max_bounces=max_bounces)])
+    wl = workloads.workload("c3")
+    check(renderer, oracle, tables, wl["flat"], wl["camera"], [make_params(96, 54, spp=2, max_bounces=max_bounces)])
+
+
 def test_mesh_scene_small_frame(renderer, oracle, tables):
     """configs[2] stand-in: default list + 960 triangles"""
     wl = workloads.workload("c3")
