@@ -111,12 +111,13 @@ def cpu_baseline(wl, tables, budget_s=15.0):
     }
 
 
-def kernel_variant(flat, flat_scan=False):
-    """which instantiation of render_tiles the library picks for this scene"""
+def kernel_variant(flat, flat_scan=False, max_bounces=10):
+    """which instantiation of render_tiles the library picks for this scene: <scan modes, largest depth
+    budget> (scenes with a box tree have a kernel for up to 10 bounces and one for up to 16)"""
     c = flat.counts
     tree = (c["n_spheres"] >= 64 or c["n_tris"] >= 64) and not flat_scan
     rej = 32 <= c["n_spheres"] < 64 or (flat_scan and c["n_spheres"] >= 32)
-    return "render_tiles<%d>" % ((2 if tree else 0) | (1 if rej else 0))
+    return "render_tiles<%d, %d>" % ((2 if tree else 0) | (1 if rej else 0), 10 if tree and max_bounces <= 10 else 16)
 
 
 def counters_from_profile(key):
@@ -206,7 +207,7 @@ def flat_scan_probe(r, wl, flops_seg):
     seg = r.ray_count() - seg0
     r.set_scene(wl["flat"])
     achieved = flops_seg * seg / (ms * 1e-3) / 1e12
-    return {"kernel": "render_tiles<1>", "kernel_ms": round(ms, 3), "mrays_per_s": round(seg / ms / 1e3, 3),
+    return {"kernel": "render_tiles<1, 16>", "kernel_ms": round(ms, 3), "mrays_per_s": round(seg / ms / 1e3, 3),
             "algorithmic_tflops": round(achieved, 3),
             "of_fp32_peak": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4),
             "sample": "8 spp of the full frame, %d segments; every sphere of the list tested for every segment "
