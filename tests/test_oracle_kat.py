@@ -139,6 +139,28 @@ def test_cube_edge_gives_diagonal_normal(oracle, tables):
     assert np.array_equal(r["normal"], np.array([s, 0, s], dtype=f32))
 
 
+def test_cube_normal_cast_saturates_and_turns_nan_into_zero(oracle, tables):
+    """The normal's components are `(1.0001 * (p - c) / half_width) as i32` (:211-215); Rust's cast
+    saturates and maps NaN to 0 (an x86 `cvttss2si` would give i32::MIN for both).
+    Plate of thickness 2^-100 at x = -2^-30, ray along +x from (-3, .25, .25): both x bounds are
+    (3 - 2^-30)/1 = 3, p = (0, .25, .25), p.x - c.x = 2^-30, quotient 1.0001 * 2^71 -> i32::MAX, which as
+    f32 is 2^31; y and z give trunc(0.250025) = 0; unit((2^31, 0, 0)) = (1, 0, 0)."""
+    plate = Cube((-2.0 ** -30, 0.0, 0.0), 2.0 ** -100, 2.0, 2.0, Lambertian((0.5, 0.5, 0.5)))
+    r = oracle.trace_one(one(plate), zero_screen(tables), (-3.0, 0.25, 0.25), (1.0, 0.0, 0.0))
+    assert r["hit"] and r["t"] == f32(3.0)
+    assert np.array_equal(r["p"], np.array([0, 0.25, 0.25], dtype=f32))
+    assert np.array_equal(r["normal"], np.array([1, 0, 0], dtype=f32))
+    # the same plate on the other side of x = 0: -1.0001 * 2^71 -> i32::MIN
+    plate = Cube((2.0 ** -30, 0.0, 0.0), 2.0 ** -100, 2.0, 2.0, Lambertian((0.5, 0.5, 0.5)))
+    r = oracle.trace_one(one(plate), zero_screen(tables), (-3.0, 0.25, 0.25), (1.0, 0.0, 0.0))
+    assert r["hit"] and np.array_equal(r["normal"], np.array([-1, 0, 0], dtype=f32))
+    # no thickness at all, plate through the hit point: 1.0001 * 0 / 0 = NaN -> 0, so the vector
+    # is (0, 0, 0) and unit_vector divides 0 by 0 in every component
+    plate = Cube((0.0, 0.0, 0.0), 0.0, 2.0, 2.0, Lambertian((0.5, 0.5, 0.5)))
+    r = oracle.trace_one(one(plate), zero_screen(tables), (-3.0, 0.25, 0.25), (1.0, 0.0, 0.0))
+    assert r["hit"] and r["t"] == f32(3.0) and np.isnan(r["normal"]).all()
+
+
 def test_cube_tie_keeps_earlier(oracle, tables):
     """`tmin < t_max` is strict: a cube at exactly the current closest t loses"""
     flat = one(CUBE)
