@@ -220,6 +220,7 @@ int rt_upload_scene(rt_ctx *ctx, const rt_scene *s) {
     d.lds_run = hs.lds_run; d.lds_level = hs.lds_level;
     d.lds_first = hs.lds_first; d.lds_count = hs.lds_count;
     d.lds_deep_level = hs.lds_deep_level; d.lds_deep_first = hs.lds_deep_first; d.lds_deep_count = hs.lds_deep_count;
+    d.lds_kind = hs.lds_kind;
     d.modes = hs.modes;
     d.cheap_ok = hs.cheap_ok;
     if ((rc = upload(c, hs.runs, &d.runs)) != RT_OK || (rc = upload(c, hs.sph_geom, &d.sph_geom)) != RT_OK ||

@@ -71,6 +71,7 @@ struct DevScene {
     uint32_t lds_run, lds_level, lds_first, lds_count;
     // the same for a launch with the deep material stack (less room): the launch copies them over the four above
     uint32_t lds_deep_level, lds_deep_first, lds_deep_count;
+    uint32_t lds_kind;        // DEV_SPHERE or DEV_TRI: what run lds_run, the scene's largest tree, holds
     uint32_t modes;           // bit 0: some run is RUN_FLAT, bit 1: some run is RUN_TREE
     uint32_t cheap_ok;        // every sphere has finite |centre| <= 2^30 and 2^-30 <= |radius| <= 2^30: rays of
                               // moderate origin and length may take the short division and root sequences

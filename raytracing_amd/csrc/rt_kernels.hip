@@ -228,14 +228,17 @@ __host__ __device__ constexpr int occ_hint_of(int modes) { return modes == 0 ? R
 // (64-sample launches of the whole frame, 1 / 16 / 24 / 32 lanes: default scene 1080p 4.97 / 4.70 / 4.57 /
 // 4.58 ms; with a tree 8 / 16 / 20 / 24 / 32 lanes: 10,000 spheres 4K 107.8 / 105.6 / 105.6 / 106.4 /
 // 107.6 ms, a million triangles 53.9 / 51.4 / 50.5 / 50.3 / 50.3, 960-triangle mesh 10.35 / 10.08 / 9.97 /
-// 9.94 / 9.97)
+// 9.94 / 9.97; with the final kernel of round 2, 20 / 24 lanes: 10,000 spheres 98.9 / 99.1 ms, a million
+// triangles 46.8 / 46.2, mesh 9.27 / 9.20: a scene whose largest tree holds triangles waits for 24)
 #ifndef RTK_FETCH_MIN0
 #define RTK_FETCH_MIN0 24
 #endif
 #ifndef RTK_FETCH_MIN
 #define RTK_FETCH_MIN 20
 #endif
-__host__ __device__ constexpr uint32_t fetch_min_of(int modes) { return modes == 0 ? RTK_FETCH_MIN0 : RTK_FETCH_MIN; }
+#ifndef RTK_FETCH_MIN_TRI
+#define RTK_FETCH_MIN_TRI 24
+#endif
 constexpr int TILE = 8;   // 8x8 pixels per wavefront
 
 struct TreeTable {
@@ -1154,7 +1157,7 @@ __device__ __forceinline__ V3 sky(V3 ud, bool gamma) {
 constexpr uint32_t ITEM_BITS = DEV_STAGE_ITEM_BITS;   // item index inside a unit: pixels of the unit x samples of the launch <= 512
 
 // the arguments of render_tiles as they lie in the kernel's argument block
-struct KernArgs { DevScene dsc; rt_camera cam; rt_params p; DevFrame fr; uint32_t n_bands, unit_px_log2, stretch_unit; };
+struct KernArgs { DevScene dsc; rt_camera cam; rt_params p; DevFrame fr; uint32_t n_bands, unit_px_log2, stretch_unit, fetch_min; };
 
 template <int MODES, int DEPTH>
 // Two 8-wave workgroups per CU: four waves per SIMD, at most 128 VGPRs each (some per-item
@@ -1461,11 +1464,12 @@ void render_tiles(KernArgs by_value) {
         const unsigned long long tm3 = __builtin_readcyclecounter();
 #endif
         // Finished items are counted against their units, and their lanes given new items, once
-        // fetch_min_of(MODES) lanes stand idle (or all that are left): both steps cost the wave the
+        // fetch_min lanes stand idle (or all that are left): both steps cost the wave the
         // same whether one lane takes part or all.
         parked = parked || done;
         const unsigned long long idle = __builtin_amdgcn_ballot_w64(!alive);
-        const bool refill = idle != 0ull && ((uint32_t)__builtin_popcountll(idle) >= fetch_min_of(MODES) || (idle | ~__builtin_amdgcn_ballot_w64(true)) == ~0ull);
+        const uint32_t fetch_min = MODES == 0 ? (uint32_t)RTK_FETCH_MIN0 : args()->fetch_min;   // chosen per launch, see rtk_launch_render
+        const bool refill = idle != 0ull && ((uint32_t)__builtin_popcountll(idle) >= fetch_min || (idle | ~__builtin_amdgcn_ballot_w64(true)) == ~0ull);
         if (refill && parked) {
             // attenuation * ray_colour(...), innermost product first (src/raytracer.rs:79)
             // (four entries per round: their fetches overlap, the products keep their order)
@@ -1741,7 +1745,10 @@ hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_
     // used only while much is left, and only by the kernels with a tree: 10,000 spheres 4K -0.4 %, a
     // million triangles -1 %.
     const uint64_t stretch_unit = std::min<uint64_t>(32u * groups * waves, 0x1fffffffu);
-    rtk::KernArgs ka{sc, cam, p, fr, n_bands, r, (uint32_t)stretch_unit};
+    // idle lanes a wave waits for before it hands out new work items
+    const uint32_t fetch_min = (sc.modes & 3u) == 0u ? RTK_FETCH_MIN0
+                               : ((sc.modes & 2u) && sc.lds_kind == DEV_TRI) ? RTK_FETCH_MIN_TRI : RTK_FETCH_MIN;
+    rtk::KernArgs ka{sc, cam, p, fr, n_bands, r, (uint32_t)stretch_unit, fetch_min};
     if (p.max_bounces > RT_MAX_BOUNCES) return hipErrorInvalidValue;
     const uint32_t which = kernel_index(sc.modes, p.max_bounces);
     if (which >= 4u) {

@@ -454,7 +454,7 @@ int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::strin
         };
         const uint32_t L = levels_that_fit(DEV_TREE_LDS_F4), Ld = levels_that_fit(DEV_TREE_LDS_F4_DEEP);
         if (L == 0xffffffffu) continue;
-        sc.lds_run = r; sc.lds_level = L;
+        sc.lds_run = r; sc.lds_level = L; sc.lds_kind = run.kind;
         sc.lds_first = run.level_base[L];
         sc.lds_count = end - run.level_base[L];
         sc.lds_deep_level = 0xffffffffu; sc.lds_deep_first = 0; sc.lds_deep_count = 0;

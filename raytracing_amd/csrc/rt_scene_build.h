@@ -21,6 +21,7 @@ struct HostScene {
     uint32_t cheap_ok = 1;            // see DevScene::cheap_ok
     uint32_t lds_run = 0xffffffffu, lds_level = 0, lds_first = 0, lds_count = 0;
     uint32_t lds_deep_level = 0xffffffffu, lds_deep_first = 0, lds_deep_count = 0;   // see DevScene
+    uint32_t lds_kind = 0;
     uint32_t modes = 0;
 };
 
