@@ -268,6 +268,11 @@ struct Lds {
     float uv[4];                                        // width - 1, height - 1, their refined reciprocals
 };
 
+// two 8-wave workgroups of a tree kernel share a CU's 160 KiB of LDS
+static_assert(2u * sizeof(Lds<2, (int)DEV_STACK_SHALLOW>) <= 160u * 1024u && 2u * sizeof(Lds<3, (int)DEV_STACK_SHALLOW>) <= 160u * 1024u &&
+              2u * sizeof(Lds<2, (int)RT_MAX_BOUNCES>) <= 160u * 1024u && 2u * sizeof(Lds<3, (int)RT_MAX_BOUNCES>) <= 160u * 1024u,
+              "DEV_TREE_LDS_F4 / DEV_TREE_LDS_F4_DEEP leave no room for two workgroups per CU");
+
 struct Ray { V3 o, d; };
 
 // Camera::get_ray, src/camera/mod.rs:75-79
