@@ -304,6 +304,19 @@ int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::strin
 
     const double LEAF_EPS_SPHERE = 1.0 / 65536.0;   // proven bound of the kernel's test, see cull_pair
 
+    // A scene that gets a tree anyway gives its middling sphere runs (DEV_CULL_MIN_RUN and more) a
+    // tree as well: the kernel for scenes with both kinds of long runs is the one that does not fit
+    // the vector register file without spills, and a small tree costs a ray no more than the
+    // rejection scan of the whole run.
+    uint32_t sphere_tree_min = DEV_TREE_MIN_RUN;
+    for (uint32_t id = 0; id < n && use_tree;) {
+        uint32_t end = id;
+        while (end < n && list[end].kind == list[id].kind) ++end;
+        if ((list[id].kind == DEV_SPHERE || list[id].kind == DEV_TRI) && end - id >= DEV_TREE_MIN_RUN)
+            sphere_tree_min = DEV_CULL_MIN_RUN;
+        id = end;
+    }
+
     for (uint32_t id = 0; id < n;) {
         const int kind = list[id].kind;
         uint32_t end = id;
@@ -324,7 +337,7 @@ int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::strin
                 const uint32_t src = list[id + k].k;
                 balls[k] = bounded_or_unbounded({s->sph_cx[src], s->sph_cy[src], s->sph_cz[src], s->sph_r[src]});
             }
-            if (count >= DEV_TREE_MIN_RUN && use_tree) {
+            if (count >= sphere_tree_min && use_tree) {
                 run.mode = RUN_TREE;
                 order = tree_order(balls);
             } else if (count >= DEV_CULL_MIN_RUN) {
