@@ -1,21 +1,21 @@
 #!/usr/bin/env python3
 """bench.py - throughput of the render loop on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4] [--spp-per-step 64]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4] [--spp-per-step S]
 
 With --gpus N > 1 and no WORLD_SIZE in the environment the script starts its own N ranks
 (one process per GPU, `torch.distributed.run` on 127.0.0.1) before anything touches HIP,
 relays rank 0's JSON line and fails if any rank fails - the stand-in for the reference's
 thread fan-out (src/raytracer.rs:146-171).  Launched under torch.distributed.run it is one rank.
 
-A step is one pass of the hot path over the whole frame: `spp-per-step` samples
-of every pixel, added into the per-pixel sums (the progressive form of
-calculate_some_pxls, src/raytracer.rs:232-271), followed by the quantiser and,
-with N > 1 GPUs, one RCCL all-gather of the packed bands.  The default workload
-is the one the headline metric is quoted on: 10,000 random spheres at 3840x2160,
-256 spp; with the defaults (8 steps of 64 spp, one kernel launch each) the timed region
-is exactly two such frames.  The frame is split over the N ranks by interleaved 8-row bands
-(strong scaling: the total work is fixed).
+A step is one pass of the hot path over the whole frame: by default all samples of every pixel
+(the whole of calculate_some_pxls, src/raytracer.rs:232-271, for one frame; `--spp-per-step` renders
+a part of them per step, the progressive form), followed by the quantiser and, with N > 1 GPUs, one
+RCCL all-gather of the packed bands.  The default workload is the one the headline metric is quoted
+on: 10,000 random spheres at 3840x2160, 256 spp - one kernel launch per step, so `ms_per_step` is
+the metric's ms per frame.  The frame is split over the N ranks by interleaved 8-row bands (strong
+scaling: the total work is fixed).  With N > 1 the line also carries, per rank, kernel time, segments
+and the time of the fan-in (`config.ranks`).
 
 Rank 0 prints ONE JSON line.  `value` is Mrays/s over all ranks, a ray being one
 path segment (one closest-hit query over the list), counted on the device.
@@ -77,23 +77,46 @@ def launch_ranks(args):
     sys.exit(0)
 
 
+def host_cores():
+    """Threads the CPU baseline may use: the CPUs this process is allowed on (its affinity mask, what
+    `nproc` prints), cut to a cgroup CPU quota if one is set, and to the 256 threads the oracle takes."""
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()[:2]
+        if q != "max":
+            quota = max(1, int(int(q) / int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(allowed, quota or allowed, 256)), allowed, quota
+
+
 def cpu_baseline(wl, tables, budget_s=15.0):
     """The CPU oracle (a C restatement of the reference's loop, row-interleaved
-    threads like src/raytracer.rs:245) on a bounded sample of the same workload:
-    1 spp of every 64th band of the frame, band after band until the time budget is used."""
+    threads like src/raytracer.rs:245, one per host core) on a bounded sample of the same workload:
+    1 spp of every `stride`-th band of the frame, band set after band set until the time budget is used."""
     from raytracing_amd import make_params
     from tests import oracle_lib
 
     orc = oracle_lib.load()
-    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16), 64)
+    cores, allowed, quota = host_cores()
     w, h = wl["width"], wl["height"]
     total_bands = (h + 7) // 8
+    # a call renders the rows of total_bands / stride bands; every thread should get a few of them
     stride = 64
+    while stride > 1 and (total_bands // stride) * 8 < 2 * cores:
+        stride //= 2
     accum = np.zeros((h, w, 4), dtype=np.float32)
     seg = 0
     bands = 0
     t0 = time.perf_counter()
-    for begin in [32, 0, 48, 16, 8, 40, 24, 56] + [b for b in range(64) if b % 8]:
+    # (bit-reversed order: the band sets taken so far are spread evenly over the frame)
+    order = sorted(range(stride), key=lambda b: int(format(b, "06b")[::-1], 2))
+    for begin in order:
         if begin >= total_bands:
             continue
         p = make_params(w, h, spp=wl["spp"], sample_begin=0, sample_count=1, band_begin=begin,
@@ -106,55 +129,69 @@ def cpu_baseline(wl, tables, budget_s=15.0):
     dt = time.perf_counter() - t0
     return {
         "value": round(seg / dt / 1e6, 5), "unit": "Mrays/s", "cores": cores, "kind": "port",
-        "sample": "%d of %d 8-row bands of the %dx%d frame at 1 of %d spp, %d segments in %.1f s"
-                  % (bands, total_bands, w, h, wl["spp"], seg, dt),
+        "host": {"cpus_allowed": allowed, "cpu_count": os.cpu_count(), "cgroup_cpu_quota": quota},
+        "sample": "%d of %d 8-row bands of the %dx%d frame at 1 of %d spp, %d segments in %.1f s on %d threads"
+                  % (bands, total_bands, w, h, wl["spp"], seg, dt, cores),
     }
 
 
-def kernel_variant(flat, flat_scan=False, max_bounces=10):
-    """which instantiation of render_tiles the library picks for this scene: <scan modes, largest depth
-    budget> (scenes with a box tree have a kernel for up to 10 bounces and one for up to 16)"""
-    c = flat.counts
-    tree = (c["n_spheres"] >= 64 or c["n_tris"] >= 64) and not flat_scan
-    rej = 32 <= c["n_spheres"] < 64 or (flat_scan and c["n_spheres"] >= 32)
-    return "render_tiles<%d, %d>" % ((2 if tree else 0) | (1 if rej else 0), 10 if tree and max_bounces <= 10 else 16)
+def library_build_id():
+    from raytracing_amd import _lib
+    return _lib.load().rt_build_id().decode()
+
+
+def profile_record(fname, key):
+    """One workload's record of a committed counter file under profiles/ (tools/collect_counters.py), and
+    why it cannot be used, if so: absent, or taken on a library built from other kernel sources than the
+    one being benched (rt_build_id)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", fname)) as f:
+            rec = json.load(f)[key]
+    except (OSError, ValueError, KeyError, TypeError):
+        return None, "no committed counter pass for this workload in profiles/" + fname
+    have, want = rec.get("library_build"), library_build_id()
+    if have != want:
+        return None, "profiles/%s[%s] was taken on library build %s, this is %s" % (fname, key, have, want)
+    return rec, None
 
 
 def counters_from_profile(key):
     """Per-segment VALU figures of the render kernel on one workload from the committed rocprofv3
-    --pmc passes (profiles/sq_counters.json, written by tools/collect_counters.py); None if absent."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "sq_counters.json")) as f:
-            rec = json.load(f)[key]
-        return rec if rec.get("valu_lane_ops_per_segment") else None
-    except (OSError, ValueError, KeyError, TypeError):
-        return None
+    --pmc passes (profiles/sq_counters.json); (None, reason) if they do not belong to this build."""
+    rec, why = profile_record("sq_counters.json", key)
+    if rec is not None and not rec.get("valu_lane_ops_per_segment"):
+        return None, "record without lane operations"
+    return rec, why
 
 
 def hbm_traffic_from_profile(key, spp_per_launch):
     """HBM bytes per launch of render_tiles from the committed rocprofv3 --pmc passes
-    (profiles/hbm_traffic.json, tools/collect_counters.py); None if absent or taken at another launch size."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-            rec = json.load(f)[key]
-        return rec["bytes_per_launch"] if rec.get("spp_per_launch") == spp_per_launch else None
-    except (OSError, ValueError, KeyError, TypeError):
+    (profiles/hbm_traffic.json); None if absent, from another build or another launch size."""
+    rec, _ = profile_record("hbm_traffic.json", key)
+    if rec is None or rec.get("spp_per_launch") != spp_per_launch:
         return None
+    return rec["bytes_per_launch"]
 
 
 def valu_roofline(key, kernel, segments_per_launch, kernel_ms, spp_per_launch, flops_seg, flat):
     """`roofline` object for one kernel launch size: executed VALU lane-operations against the rate
     the chip issues them (see the module docstring); the counter-derived parts are None when no
     committed counter pass covers this workload."""
-    prof = counters_from_profile(key)
+    prof, why_not = counters_from_profile(key)
     seg_per_s = segments_per_launch / (kernel_ms * 1e-3)
+    traffic = hbm_traffic_from_profile(key, spp_per_launch)
     out = {"bound": "valu", "achieved": None, "peak": PEAK_VALU_LANE_TOPS, "unit": "TFLOP/s", "frac": None,
-           "traffic": hbm_traffic_from_profile(key, spp_per_launch),
-           "kernel": kernel, "kernel_ms": round(float(kernel_ms), 3),
+           "traffic": traffic,
+           # the HBM side of the same launch: bytes moved / kernel time against the 8 TB/s peak
+           "hbm_gbps": None if traffic is None else round(traffic / (kernel_ms * 1e-3) / 1e9, 1),
+           "hbm_frac_of_8TBps": None if traffic is None else round(traffic / (kernel_ms * 1e-3) / 8e12, 4),
+           "kernel": kernel, "kernel_ms": round(float(kernel_ms), 3), "library_build": library_build_id(),
            "definition": "achieved = executed VALU lane-operations per second in units of 1e12 (a lane-operation "
                          "is one lane of one vector instruction = at most one unfused flop; an FMA counts once); "
                          "peak = 1024 SIMDs x 32 lanes/clk x 2.4 GHz"}
-    if prof is not None:
+    if prof is None:
+        out["frac_null_because"] = why_not
+    else:
         lane_ops = prof["valu_lane_ops_per_segment"] * seg_per_s / 1e12
         out["achieved"] = round(lane_ops, 3)
         out["frac"] = round(lane_ops / PEAK_VALU_LANE_TOPS, 4)
@@ -179,9 +216,9 @@ def valu_roofline(key, kernel, segments_per_launch, kernel_ms, spp_per_launch, f
         "flops_per_segment": flops_seg, "tflops": round(alg, 3),
         "of_fp32_peak": round(alg / PEAK_FP32_VECTOR_TFLOPS, 4),
         "note": "work of the reference's linear scan (18/sphere + 14/plane + 18/cube + 45/triangle + 80 per "
-                "segment, mul/add counted singly) x segments / kernel time; a box tree (scenes with >= 64 spheres "
-                "or triangles) skips most of it, so this is not a utilisation there",
-        "tree": bool(c["n_spheres"] >= 64 or c["n_tris"] >= 64),
+                "segment, mul/add counted singly) x segments / kernel time; a box tree (scenes with a run of >= 32 "
+                "spheres or >= 64 triangles) skips most of it, so this is not a utilisation there",
+        "tree": kernel.startswith("render_tiles<2") or kernel.startswith("render_tiles<3"),
     }
     return out
 
@@ -205,9 +242,10 @@ def flat_scan_probe(r, wl, flops_seg):
     r.render(make_params(w, h, spp=spp, sample_begin=1, sample_count=8))
     ms = r.timer_stop()
     seg = r.ray_count() - seg0
+    kernel = r.kernel_variant()
     r.set_scene(wl["flat"])
     achieved = flops_seg * seg / (ms * 1e-3) / 1e12
-    return {"kernel": "render_tiles<1, 16>", "kernel_ms": round(ms, 3), "mrays_per_s": round(seg / ms / 1e3, 3),
+    return {"kernel": kernel, "kernel_ms": round(ms, 3), "mrays_per_s": round(seg / ms / 1e3, 3),
             "algorithmic_tflops": round(achieved, 3),
             "of_fp32_peak": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4),
             "sample": "8 spp of the full frame, %d segments; every sphere of the list tested for every segment "
@@ -215,43 +253,72 @@ def flat_scan_probe(r, wl, flops_seg):
 
 
 def other_workload(name, tables, launches=3):
-    """A short single-GPU measurement of another configuration: `launches` launches of up to 64 spp of
-    the full frame after one warm-up, kernel time from HIP events."""
+    """A short single-GPU measurement of another configuration: `launches` launches of up to 256 spp of
+    the full frame after one warm-up, kernel time from HIP events.  A workload that is a run of several
+    frames (c1: the reference's ten) is rendered the way the library offers for that, all frames in one
+    rt_render_frames launch; the time of its first frame alone in a launch of its own is given beside it."""
     from raytracing_amd import Renderer, make_params, workloads
     wl = workloads.workload(name)
     w, h, spp = wl["width"], wl["height"], wl["spp"]
-    sps = min(64, spp)
+    sps = min(256, spp)
+    cams = wl.get("cameras")
+    n_frames = len(cams) if cams else 1
     flops_seg = workloads.flops_per_segment(wl["flat"])
     with Renderer(0, tables) as r:
-        r.set_scene(wl["flat"]); r.set_camera(wl["camera"]); r.begin_frame(w, h)
-        r.render(make_params(w, h, spp=spp, sample_begin=0, sample_count=sps))
+        r.set_scene(wl["flat"]); r.set_camera(wl["camera"]); r.begin_frames(w, h, n_frames)
+        kernel = r.kernel_variant()
+
+        def launch(begin):
+            p = make_params(w, h, spp=spp, sample_begin=begin, sample_count=sps)
+            if cams:
+                r.render_frames(p, cams)
+            else:
+                r.render(p)
+
+        launch(0)
         r.sync()
-        r.begin_frame(w, h)
+        r.begin_frames(w, h, n_frames)
         seg0 = r.ray_count()
         ms = []
         for k in range(launches):
             r.timer_start()
-            r.render(make_params(w, h, spp=spp, sample_begin=(k * sps) % max(1, spp - sps + 1), sample_count=sps))
+            launch((k * sps) % max(1, spp - sps + 1))
             ms.append(r.timer_stop())
         seg = r.ray_count() - seg0
+        alone = None
+        if cams:
+            one = []
+            for k in range(launches + 1):
+                r.timer_start()
+                r.render(make_params(w, h, spp=spp, sample_begin=0, sample_count=sps))
+                one.append(r.timer_stop())
+            alone = {"kernel_ms": round(float(np.mean(one[1:])), 4),
+                     "mrays_per_s": round(seg / launches / n_frames / float(np.mean(one[1:])) / 1e3, 3)}
     kms = float(np.mean(ms))
-    roof = valu_roofline(name, kernel_variant(wl["flat"]), seg / launches, kms, sps, flops_seg, wl["flat"])
-    return {"workload": "%s: %s" % (name, wl["description"]), "spp_per_launch": sps, "kernel_ms": round(kms, 3),
-            "mrays_per_s": round(seg / launches / kms / 1e3, 3),
-            "ms_per_frame": round(kms * spp / sps, 2),
-            "roofline_frac": roof["frac"], "valu_lane_tops": roof["achieved"],
-            "algorithmic_tflops": roof["algorithmic_equivalent"]["tflops"],
-            "algorithmic_of_fp32_peak": roof["algorithmic_equivalent"]["of_fp32_peak"],
-            "hbm_bytes_per_launch": roof["traffic"]}
+    roof = valu_roofline(name, kernel, seg / launches, kms, sps, flops_seg, wl["flat"])
+    out = {"workload": "%s: %s" % (name, wl["description"]), "spp_per_launch": sps, "kernel": kernel,
+           "frames_per_launch": n_frames, "kernel_ms": round(kms, 4 if kms < 1 else 3),
+           "mrays_per_s": round(seg / launches / kms / 1e3, 3),
+           "ms_per_frame": round(kms * spp / sps / n_frames, 4 if kms < 1 else 2),
+           "roofline_frac": roof["frac"], "valu_lane_tops": roof["achieved"],
+           "frac_null_because": roof.get("frac_null_because"),
+           "algorithmic_tflops": roof["algorithmic_equivalent"]["tflops"],
+           "algorithmic_of_fp32_peak": roof["algorithmic_equivalent"]["of_fp32_peak"],
+           "hbm_bytes_per_launch": roof["traffic"], "hbm_gbps": roof["hbm_gbps"],
+           "hbm_frac_of_8TBps": roof["hbm_frac_of_8TBps"]}
+    if alone is not None:
+        out["one_frame_per_launch"] = alone
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c4")
-    ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--spp-per-step", type=int, default=0,
+                    help="samples of every pixel one step renders (0 = the frame's spp: a step is a whole frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-flat-probe", action="store_true")
     ap.add_argument("--others", default="c1,c2,c3,c5",
@@ -287,28 +354,37 @@ def main():
     tables = load_tables()
     wl = workloads.workload(args.workload)
     w, h, spp = wl["width"], wl["height"], wl["spp"]
-    sps = max(1, min(args.spp_per_step, spp))
+    sps = max(1, min(args.spp_per_step or spp, spp))
+    launches_per_step = -(-sps // 512)       # rt_render cuts a sample range into launches of at most 512 samples
     total_bands = (h + 7) // 8
     max_bands = len(range(0, total_bands, world))
     flops_seg = workloads.flops_per_segment(wl["flat"])
 
+    cams = wl.get("cameras")                 # a run of several frames: one rt_render_frames launch per step
+    n_frames = len(cams) if cams else 1
     r = Renderer(local_rank, tables)
     r.set_scene(wl["flat"])
     r.set_camera(wl["camera"])
-    r.begin_frame(w, h)
+    r.begin_frames(w, h, n_frames)
+    kernel = r.kernel_variant()
     block = torch.zeros((max_bands * 8, w), dtype=torch.int32, device="cuda")
     gathered = torch.zeros((world * max_bands * 8, w), dtype=torch.int32, device="cuda") if world > 1 else None
     frame = [None]
 
     def step(k):
-        """samples [k*sps, (k+1)*sps) modulo the frame's spp, so any number of steps is valid"""
+        """samples [k*sps, (k+1)*sps) modulo the frame's spp, so any number of steps is valid; returns the
+        kernel time (HIP events on the library's stream around the launches) and the time of the fan-in
+        (quantise this rank's bands, all-gather, put the picture together), both in ms"""
         begin = (k % max(1, spp // sps)) * sps
         p = make_params(w, h, spp=spp, sample_begin=begin, sample_count=sps, band_begin=rank,
                         band_stride=world)
         r.timer_start()
-        r.render(p)
-        ms = r.timer_stop()          # HIP events on the library's stream around the launch
-        torch.cuda.current_stream().synchronize()   # the previous step's gather has read `block`
+        if cams:
+            r.render_frames(p, cams)
+        else:
+            r.render(p)
+        ms = r.timer_stop()
+        t1 = time.perf_counter()
         r.export_packed_bands(block.data_ptr(), block.numel(), rank, world)
         r.sync()
         if world > 1 and rehearsal:
@@ -319,7 +395,8 @@ def main():
             dist.all_gather_into_tensor(gathered, block)
         if world > 1:
             frame[0] = multi_gpu.compose(gathered.view(world, max_bands * 8, w), h)   # display order, every rank
-        return ms
+            torch.cuda.current_stream().synchronize()    # the gather has read `block` before the next step writes it
+        return ms, (time.perf_counter() - t1) * 1e3
 
     def barrier():
         torch.cuda.synchronize()
@@ -329,23 +406,38 @@ def main():
 
     for k in range(args.warmup):
         step(k)
-    r.begin_frame(w, h)              # timed steps start from zeroed sums
+    r.begin_frames(w, h, n_frames)   # timed steps start from zeroed sums
     barrier()
     seg0 = r.ray_count()
-    kernel_ms = []
+    kernel_ms, fanin_ms = [], []
     t0 = time.perf_counter()
     for k in range(args.steps):
-        kernel_ms.append(step(k))
+        a, b = step(k)
+        kernel_ms.append(a); fanin_ms.append(b)
+    t_own = time.perf_counter() - t0       # this rank's steps, before it waits for the others
     barrier()
     dt = time.perf_counter() - t0
     seg = r.ray_count() - seg0
 
+    ranks = None
     if world > 1:
-        t = torch.tensor([dt, float(seg), float(np.mean(kernel_ms))], dtype=torch.float64,
-                         device="cpu" if rehearsal else "cuda")
-        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt = float(tmax[0]); seg_total = int(tsum[1])
+        # per rank: wall time of its steps, segments, kernel time and fan-in time per step - what tells an
+        # uneven split (segments, kernel time) from launch tails (kernel time against its share of the
+        # one-GPU time) and from the gather (fan-in time) when the scaling falls short
+        mine = torch.tensor([dt, float(seg), float(np.mean(kernel_ms)), float(np.max(kernel_ms)),
+                             float(np.mean(fanin_ms)), t_own], dtype=torch.float64,
+                            device="cpu" if rehearsal else "cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        every = torch.stack(every).cpu().numpy()
+        dt = float(every[:, 0].max()); seg_total = int(every[:, 1].sum())
+        spread = lambda col: {"min": round(float(every[:, col].min()), 3), "mean": round(float(every[:, col].mean()), 3),
+                              "max": round(float(every[:, col].max()), 3)}
+        ranks = {"kernel_ms_per_step": spread(2), "kernel_ms_slowest_step": spread(3),
+                 "fan_in_ms_per_step": spread(4), "own_steps_s": spread(5),
+                 "segments_per_step": {"min": int(every[:, 1].min() / args.steps), "mean": int(every[:, 1].mean() / args.steps),
+                                       "max": int(every[:, 1].max() / args.steps)},
+                 "fan_in": "quantise own bands + all_gather of packed pixels + compose, wall clock per step"}
     else:
         seg_total = seg
 
@@ -372,11 +464,12 @@ def main():
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        paths = w * h * sps * args.steps
+        paths = w * h * sps * args.steps * n_frames
         # roofline of the dominant kernel (render_tiles) on THIS rank, from its mean launch
         # duration (HIP events) and its segments per launch
-        roof = valu_roofline(args.workload, kernel_variant(wl["flat"]), seg / args.steps, float(np.mean(kernel_ms)),
-                             sps, flops_seg, wl["flat"])
+        n_launch = args.steps * launches_per_step
+        roof = valu_roofline(args.workload, kernel, seg / n_launch, float(np.sum(kernel_ms)) / n_launch,
+                             -(-sps // launches_per_step), flops_seg, wl["flat"])
         out = {
             "metric": METRIC,
             "value": round(seg_total / dt / 1e6, 3),
@@ -390,8 +483,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "%s: %s" % (args.workload, wl["description"]),
-                "spp_per_step": sps, "steps_per_frame": spp // sps,
-                "ms_per_frame": round(ms_per_step * (spp / sps), 1),
+                "spp_per_step": sps, "steps_per_frame": round(spp / sps, 3), "launches_per_step": launches_per_step,
+                "frames_per_step": n_frames,
+                "ms_per_frame": round(ms_per_step * (spp / sps) / n_frames, 4 if ms_per_step < 10 else 1),
                 "mpaths_per_s": round(paths / dt / 1e6, 3),
                 "segments_per_path": round(seg_total / paths, 4),
                 "segments_per_step": int(round(seg_total / args.steps)),
@@ -403,6 +497,8 @@ def main():
             },
             "roofline": roof,
         }
+        if ranks is not None:
+            out["config"]["ranks"] = ranks
         if flat is not None:
             out["roofline"]["flat_scan"] = flat
         if world == 1 and args.others:

@@ -64,6 +64,7 @@ enum { RT_METAL = 0, RT_LAMBERTIAN = 1, RT_DIELECTRIC = 2 };
 enum { RT_SAMPLING_DET = 0 };
 
 #define RT_BAND_ROWS 8u      /* rows per band = tile height of one wavefront */
+#define RT_MAX_FRAMES 4096u  /* frames one rt_begin_frames may hold */
 #define RT_MAX_BOUNCES 16u   /* the reference uses 10 (src/raytracer.rs:132) */
 
 /*
@@ -153,6 +154,22 @@ int rt_set_camera(rt_ctx *ctx, const rt_camera *cam);
 /* (re)allocate the per-pixel buffers for width x height and zero the sums:
  * `let mut px_colour = colour::new(0,0,0)`, src/raytracer.rs:249 */
 int rt_begin_frame(rt_ctx *ctx, uint32_t width, uint32_t height);
+/* The reference renders NUM_FRAMES_TO_RENDER = 10 frames in a row and moves the camera between
+ * them (src/raytracer.rs:32,165-168,190; Scene::move_cam, src/scene/mod.rs:78-83).
+ * rt_begin_frames is rt_begin_frame for n_frames frames of one size at once: the per-pixel buffers
+ * hold them one after the other and all are zeroed; rt_begin_frame(w, h) = rt_begin_frames(w, h, 1).
+ * rt_select_frame names the frame that rt_render, rt_pack, the rt_read_* calls,
+ * rt_device_buffers, rt_export_packed_bands and rt_gather_packed work on (0 after a begin). */
+int rt_begin_frames(rt_ctx *ctx, uint32_t width, uint32_t height, uint32_t n_frames);
+int rt_select_frame(rt_ctx *ctx, uint32_t frame);
+/* rt_render for frames 0..n_frames-1 at once, frame f seen through cameras[f] (host memory, copied
+ * before the call returns; the camera of rt_set_camera is not used): the same sums, ids and
+ * segment count as n_frames calls of rt_set_camera + rt_select_frame + rt_render.  For a scene
+ * without long runs (fewer than 32 spheres and 64 triangles in a row, the reference's own scene)
+ * the frames share ONE launch: a frame as small as the reference's 600 x 337 at one sample per pixel
+ * does not fill the GPU, and ten of them in a launch take a fifth of the time of ten launches.
+ * Other scenes are rendered frame after frame.  Asynchronous on the context's stream. */
+int rt_render_frames(rt_ctx *ctx, const rt_params *params, const rt_camera *cameras, uint32_t n_frames);
 /* enqueue the render loop for the bands and samples named in params; adds into
  * the per-pixel sums (`px_colour += ray_colour(...)`, src/raytracer.rs:262).
  * Asynchronous on the context's stream. */
@@ -162,8 +179,10 @@ int rt_render(rt_ctx *ctx, const rt_params *params);
  * the reference.  It needs no rt_begin_frame: the caller owns the outputs, in device
  * memory, and the library's own working memory (the staging ring of unfinished work
  * units and the queue counters) is a fixed array inside the library's code object,
- * RT_STATIC_SCRATCH_BYTES per GPU, held from the first rt_create on that GPU until the
- * process ends.  The call makes no hipMalloc/hipFree.
+ * RT_STATIC_SCRATCH_BYTES per GPU, allocated when the code object is loaded on a GPU (the
+ * first HIP call of a process that has loaded the library, whether or not this entry point
+ * is ever used) and held until the process ends.  The call makes no hipMalloc/hipFree; it
+ * is enqueued on the context's stream (rt_device_buffers hands it out).
  *   accum_device    float4 {r,g,b,n} per pixel, display order, width*height of them;
  *                   the call ADDS the samples it renders (zero it before sample 0)
  *   ids_device      int32 per pixel, display order; written for sample 0 only
@@ -200,7 +219,11 @@ int rt_ray_count(rt_ctx *ctx, uint64_t *segments);
 /* ---- device-side access for callers that keep the image on the GPU
  * (multi-GPU gather).  Pointers stay valid until the next rt_begin_frame or
  * rt_destroy.  accum: float4 {r,g,b,n} per pixel; packed: uint32 per pixel;
- * ids: int32 per pixel; all in display order.  stream: the hipStream_t. */
+ * ids: int32 per pixel; all in display order.  stream: the hipStream_t every
+ * launch of this context is enqueued on.  Before the first rt_begin_frame the
+ * three buffers come back NULL and only the stream is valid: a caller of
+ * rt_render_static, which needs no frame, orders its own work (clearing its
+ * accum buffer, a graph capture) against that stream. */
 int rt_device_buffers(rt_ctx *ctx, void **accum, void **packed, void **ids, void **stream);
 /* quantise (write_colour, src/raytracer.rs:46-55) the bands b with
  * b % band_stride == band_begin straight into dst_device (device memory of the
@@ -219,7 +242,8 @@ int rt_export_packed_bands(rt_ctx *ctx, uint32_t *dst_device, size_t capacity_px
  * to the GPU of ctxs[0] (one peer-to-peer copy per context, each over its own xGMI
  * link), are put together there in display order and copied to `out` (host memory,
  * width*height pixels, 0x00RRGGBB).  Synchronises every context's stream work issued
- * before the call.  Errors are reported on ctxs[0]. */
+ * before the call.  Errors are reported on ctxs[0] (the text of a failure on another
+ * context is copied there). */
 int rt_gather_packed(rt_ctx *const *ctxs, uint32_t n_ctx, uint32_t *out, size_t n_px);
 /* Self-check of the library's arithmetic, no counterpart in the reference: the render
  * kernel replaces some `/` and sqrt (Rust f32 semantics, src/vector/mod.rs:141-189) by
@@ -227,6 +251,13 @@ int rt_gather_packed(rt_ctx *const *ctxs, uint32_t n_ctx, uint32_t *out, size_t 
  * size.  Runs both on about `operands` random operand sets of that range on the GPU and
  * returns the number that differ in any bit: mismatches[0] quotients, [1] roots. */
 int rt_check_arith(rt_ctx *ctx, uint64_t operands, uint32_t seed, uint64_t mismatches[2]);
+/* Which instantiation of the render kernel a launch with this depth budget runs for the
+ * uploaded scene, for profiles and bench records (no counterpart in the reference):
+ * scan_modes bit 0 = some sphere run goes through the list-order rejection scan, bit 1 = some
+ * run is walked through a box tree; depth_budget = the largest max_bounces that kernel takes. */
+int rt_kernel_info(rt_ctx *ctx, uint32_t max_bounces, uint32_t *scan_modes, uint32_t *depth_budget);
+/* First 16 hex digits of the SHA-256 of the kernel sources the library was built from. */
+const char *rt_build_id(void);
 /* HIP-event stopwatch on the context's stream; stop synchronises */
 int rt_timer_start(rt_ctx *ctx);
 int rt_timer_stop(rt_ctx *ctx, float *milliseconds);

@@ -79,6 +79,9 @@ SIGNATURES = {
     "rt_upload_scene": (C.c_int, [_vp, C.POINTER(rt_scene)]),
     "rt_set_camera": (C.c_int, [_vp, C.POINTER(rt_camera)]),
     "rt_begin_frame": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
+    "rt_begin_frames": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rt_select_frame": (C.c_int, [_vp, C.c_uint32]),
+    "rt_render_frames": (C.c_int, [_vp, C.POINTER(rt_params), C.POINTER(rt_camera), C.c_uint32]),
     "rt_render": (C.c_int, [_vp, C.POINTER(rt_params)]),
     "rt_render_static": (C.c_int, [_vp, C.POINTER(rt_params), _vp, _vp, _vp]),
     "rt_pack": (C.c_int, [_vp]),
@@ -92,6 +95,8 @@ SIGNATURES = {
     "rt_export_packed_bands": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_uint32]),
     "rt_gather_packed": (C.c_int, [_vpp, C.c_uint32, _up, C.c_size_t]),
     "rt_check_arith": (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]),
+    "rt_kernel_info": (C.c_int, [_vp, C.c_uint32, _up, _up]),
+    "rt_build_id": (C.c_char_p, []),
     "rt_timer_start": (C.c_int, [_vp]),
     "rt_timer_stop": (C.c_int, [_vp, _fp]),
     "rt_camera_new": (C.c_int, [C.c_float, C.c_float, C.c_float, C.c_float, _f3, _f3, _f3,

@@ -9,7 +9,7 @@
 //   rt_main [--width 600] [--spp 1] [--frames 10] [--aperture 0] [--bounces 10]
 //           [--no-gamma] [--seed 0] [--device 0] [--data DIR] [--out PREFIX]
 //           [--obj FILE [--obj-scale S] [--obj-at X Y Z]] [--spheres N] [--chunk N] [--quiet] [--png]
-//           [--gpus G [--same-device]]
+//           [--gpus G [--same-device]] [--batch]
 //
 // PREFIX_0000.ppm ... (.png with --png) are written when --out is given.  --chunk N renders the
 // samples of a frame N at a time (progressive); the picture is the same.
@@ -18,6 +18,8 @@
 // num_threads)` (src/raytracer.rs:245) at band height - and rt_gather_packed puts the picture
 // together on the first GPU, like the receive loop (:176-185).  --same-device keeps all G contexts
 // on --device (a rehearsal of the same code on a one-GPU box); the picture is the same either way.
+// --batch (one GPU): all frames go to the GPU in one rt_render_frames call, each with the camera position
+// the dolly has reached by then, and are read back afterwards; the pictures are the same.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -33,7 +35,7 @@ namespace {
 struct Options {
     uint32_t width = 600, spp = 1, frames = 10, bounces = 10, seed = 0, chunk = 0, spheres = 0, gpus = 1;
     int device = 0;
-    bool same_device = false;
+    bool same_device = false, batch = false;
     float aperture = 0.f, obj_scale = 1.f;
     rt::vec3 obj_at{0.f, 0.f, 0.f};
     bool gamma = true, quiet = false, png = false;
@@ -45,7 +47,7 @@ struct Options {
     std::fprintf(stderr,
                  "usage: rt_main [--width W] [--spp N] [--frames F] [--aperture A] [--bounces B] [--no-gamma]\n"
                  "               [--seed S] [--device D] [--data DIR] [--out PREFIX] [--chunk N] [--quiet] [--png]\n"
-                 "               [--obj FILE [--obj-scale S] [--obj-at X Y Z]] [--spheres N] [--gpus G [--same-device]]\n");
+                 "               [--obj FILE [--obj-scale S] [--obj-at X Y Z]] [--spheres N] [--gpus G [--same-device]] [--batch]\n");
     std::exit(2);
 }
 
@@ -66,6 +68,7 @@ Options parse(int argc, char** argv) {
         else if (a == "--device") { need(i, 1); o.device = std::atoi(argv[++i]); }
         else if (a == "--gpus") { need(i, 1); o.gpus = (uint32_t)std::strtoul(argv[++i], nullptr, 10); }
         else if (a == "--same-device") o.same_device = true;
+        else if (a == "--batch") o.batch = true;
         else if (a == "--aperture") { need(i, 1); o.aperture = std::strtof(argv[++i], nullptr); }
         else if (a == "--no-gamma") o.gamma = false;
         else if (a == "--quiet") o.quiet = true;
@@ -83,6 +86,7 @@ Options parse(int argc, char** argv) {
     }
     if (o.width < 2 || o.spp == 0) usage("--width must be >= 2 and --spp >= 1");
     if (o.gpus == 0 || o.gpus > 64) usage("--gpus must be in 1..64");
+    if (o.batch && (o.gpus != 1 || o.chunk != 0 || o.frames == 0)) usage("--batch renders whole frames on one GPU");
     return o;
 }
 
@@ -151,7 +155,43 @@ int main(int argc, char** argv) {
 
         uint64_t total_segments = 0;
         double total_ms = 0.0;
-        for (uint32_t frame = 0; frame < o.frames; ++frame) {
+        if (o.batch) {
+            // the ten frames of the reference's run (src/raytracer.rs:165-168) as one call: the camera of
+            // frame f is where Scene::move_cam has taken it after f frames
+            std::vector<rt_camera> cams;
+            uint32_t spp = o.spp;
+            for (uint32_t frame = 0; frame < o.frames; ++frame) {
+                const rt::Camera cam = o.spheres ? rt::random_spheres_camera(o.spp) : world.get_camera(o.aperture, o.spp);
+                cams.push_back(cam.c);
+                spp = cam.samples_per_px;
+                world.move_cam();
+            }
+            rt_params p;
+            std::memset(&p, 0, sizeof p);
+            p.width = image_width; p.height = image_height;
+            p.spp = spp; p.sample_begin = 0; p.sample_count = spp;
+            p.max_bounces = o.bounces; p.gamma = o.gamma ? 1u : 0u; p.t_min = 0.001f;
+            p.band_begin = 0; p.band_stride = 1;
+            p.sampling_mode = RT_SAMPLING_DET; p.seed = o.seed;
+            const auto start_time = std::chrono::steady_clock::now();
+            check(ctx[0], rt_begin_frames(ctx[0], image_width, image_height, o.frames), "rt_begin_frames");
+            check(ctx[0], rt_render_frames(ctx[0], &p, cams.data(), o.frames), "rt_render_frames");
+            check(ctx[0], rt_ray_count(ctx[0], &total_segments), "rt_ray_count");
+            total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - start_time).count();
+            for (uint32_t frame = 0; frame < o.frames; ++frame) {
+                check(ctx[0], rt_select_frame(ctx[0], frame), "rt_select_frame");
+                check(ctx[0], rt_read_packed(ctx[0], img_buffer.data(), img_buffer.size()), "rt_read_packed");
+                if (o.out.empty()) continue;
+                char name[32];
+                std::snprintf(name, sizeof name, "_%04u.%s", frame, o.png ? "png" : "ppm");
+                const std::string path = o.out + name;
+                if (o.png) check(ctx[0], rt_write_png(path.c_str(), img_buffer.data(), image_width, image_height), "rt_write_png");
+                else check(ctx[0], rt_write_ppm(path.c_str(), img_buffer.data(), image_width, image_height), "rt_write_ppm");
+            }
+            if (!o.quiet)
+                std::printf("%u frames in one call: %.3f ms, %.1f Mrays/s\n", o.frames, total_ms, (double)total_segments / total_ms * 1e-3);
+        }
+        for (uint32_t frame = 0; frame < o.frames && !o.batch; ++frame) {
             const rt::Camera cam = o.spheres ? rt::random_spheres_camera(o.spp) : world.get_camera(o.aperture, o.spp);
             const auto start_time = std::chrono::steady_clock::now();
             std::vector<uint64_t> segments(G, 0);

@@ -36,9 +36,17 @@ struct Ctx {
     bool have_cam = false;
 
     uint32_t W = 0, H = 0;
-    float4 *d_accum = nullptr;
+    uint32_t n_frames = 0, sel = 0;   // frames the per-pixel buffers hold (rt_begin_frames), and the one the
+                                      // single-frame calls work on (rt_select_frame)
+    float4 *d_accum = nullptr;        // n_frames x W x H each
     uint32_t *d_packed = nullptr;
     int32_t *d_ids = nullptr;
+    rt_camera *d_cams = nullptr;      // the cameras of the last rt_render_frames, n_frames of them
+    // the selected frame's part of the three buffers
+    size_t frame_px() const { return (size_t)W * H; }
+    float4 *accum() const { return d_accum + frame_px() * sel; }
+    uint32_t *packed() const { return d_packed + frame_px() * sel; }
+    int32_t *ids() const { return d_ids + frame_px() * sel; }
     StagedRgb *d_stage = nullptr;  // staging ring of the render launches, see DevFrame::stage
     uint32_t stage_waves = 0;      // wavefronts it has room for
     RtkStaticScratch fixed{};      // the device's static scratch (rt_render_static)
@@ -82,6 +90,8 @@ void free_frame(Ctx *c) {
     if (c->d_accum) (void)hipFree(c->d_accum);
     if (c->d_packed) (void)hipFree(c->d_packed);
     if (c->d_ids) (void)hipFree(c->d_ids);
+    if (c->d_cams) (void)hipFree(c->d_cams);
+    c->d_cams = nullptr; c->n_frames = 0; c->sel = 0;
     if (c->d_block) (void)hipFree(c->d_block);
     if (c->d_gather) (void)hipFree(c->d_gather);
     c->d_block = nullptr; c->d_gather = nullptr; c->block_px = c->gather_px = 0;
@@ -144,9 +154,7 @@ int rt_create(int device, rt_ctx **out) {
     int cus = 0;
     if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return bail(e, "hipDeviceGetAttribute");
     c->n_cus = cus > 0 ? (uint32_t)cus : 1u;
-    // staging ring: one part per wavefront a launch can have on this device (96 MiB on 256 CUs)
-    c->stage_waves = rtk_resident_waves(c->n_cus);
-    if ((e = hipMalloc(reinterpret_cast<void **>(&c->d_stage), (size_t)c->stage_waves * DEV_STAGE_WAVE_BYTES)) != hipSuccess) return bail(e, "hipMalloc");
+    // (the staging ring is allocated by the first rt_render, for the kernel its scene selects)
     // address of this device's static scratch, resolved once per device
     if ((e = rtk_static_scratch(device, &c->fixed)) != hipSuccess) return bail(e, "hipGetSymbolAddress(scratch)");
     *out = reinterpret_cast<rt_ctx *>(c);
@@ -250,26 +258,41 @@ int rt_set_camera(rt_ctx *ctx, const rt_camera *cam) {
     return RT_OK;
 }
 
-int rt_begin_frame(rt_ctx *ctx, uint32_t width, uint32_t height) {
+int rt_begin_frames(rt_ctx *ctx, uint32_t width, uint32_t height, uint32_t n_frames) {
     Ctx *c = C(ctx);
     if (!c) return RT_E_BADARG;
     if (width < 2 || height < 2 || width > 65536u || height > 65536u || (uint64_t)width * height > 0xffffffffull)
         return fail(c, RT_E_BADARG, "rt_begin_frame: width and height must be in 2..65536 and width*height below 2^32");
+    if (n_frames == 0 || n_frames > RT_MAX_FRAMES || (uint64_t)width * height * n_frames > 0xffffffffull)
+        return fail(c, RT_E_BADARG, "rt_begin_frames: n_frames must be in 1..RT_MAX_FRAMES and all frames together below 2^32 pixels");
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t n_px = (size_t)width * height;
-    if (!c->have_frame || c->W != width || c->H != height) {
+    const size_t n_px = (size_t)width * height * n_frames;
+    if (!c->have_frame || c->W != width || c->H != height || c->n_frames != n_frames) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         free_frame(c);
         HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_accum), n_px * sizeof(float4)));
         HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_packed), n_px * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_ids), n_px * sizeof(int32_t)));
-        c->W = width; c->H = height;
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_cams), n_frames * sizeof(rt_camera)));
+        c->W = width; c->H = height; c->n_frames = n_frames;
         c->have_frame = true;
     }
+    c->sel = 0;
     HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, n_px * sizeof(float4), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_packed, 0, n_px * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_ids, 0xff, n_px * sizeof(int32_t), c->stream));   // -1 = nothing recorded
     HIP_TRY(c, hipMemsetAsync(c->d_segments, 0, 8 * sizeof(unsigned long long), c->stream));
+    return RT_OK;
+}
+
+int rt_begin_frame(rt_ctx *ctx, uint32_t width, uint32_t height) { return rt_begin_frames(ctx, width, height, 1u); }
+
+int rt_select_frame(rt_ctx *ctx, uint32_t frame) {
+    Ctx *c = C(ctx);
+    if (!c) return RT_E_BADARG;
+    if (!c->have_frame) return fail(c, RT_E_STATE, "rt_select_frame: no frame");
+    if (frame >= c->n_frames) return fail(c, RT_E_BADARG, "rt_select_frame: frame beyond those of rt_begin_frames");
+    c->sel = frame;
     return RT_OK;
 }
 
@@ -293,18 +316,18 @@ static int check_render(Ctx *c, const rt_params *p, const char *who) {
 // share); otherwise the two counters behind `queue` alternate and the running launch zeroes
 // the other one.
 static int enqueue_render(Ctx *c, const rt_params *p, DevFrame fr, uint32_t stage_waves, uint32_t *queue,
-                          void *clear, size_t clear_bytes) {
+                          void *clear, size_t clear_bytes, const rt_camera *cams = nullptr, uint32_t n_frames = 1u) {
     const uint32_t n_bands = bands_of(p->height, p->band_begin, p->band_stride);
     if (n_bands == 0 || p->sample_count == 0) return RT_OK;
     rt_params part = *p;
     fr.disc_plain = c->disc_plain;
-    // development aid: RT_HIP_UNIT_PX=2|4|8|16|32|64 fixes the pixels of a tile per work unit
+    // development aid: RT_HIP_UNIT_PX=1|2|4|8|16|32|64 fixes the pixels of a tile per work unit
     // (default: by launch size, see rtk_launch_render); a unit's samples must fit a ring slot
     const char *up = std::getenv("RT_HIP_UNIT_PX");
     int unit_px_log2 = -1;
-    for (int k = 1; up && k <= 6; ++k) if (std::atoi(up) == (1 << k)) unit_px_log2 = k;
+    for (int k = 0; up && k <= 6; ++k) if (std::atoi(up) == (1 << k)) unit_px_log2 = k;
     uint32_t chunk = DEV_SAMPLE_CHUNK;
-    if (unit_px_log2 > 0) chunk = std::min<uint32_t>(chunk, (1u << DEV_STAGE_ITEM_BITS) >> unit_px_log2);
+    if (unit_px_log2 >= 0) chunk = std::min<uint32_t>(chunk, (1u << DEV_STAGE_ITEM_BITS) >> unit_px_log2);
     for (uint32_t done = 0; done < p->sample_count; done += chunk) {
         part.sample_begin = p->sample_begin + done;
         part.sample_count = std::min(chunk, p->sample_count - done);
@@ -315,9 +338,25 @@ static int enqueue_render(Ctx *c, const rt_params *p, DevFrame fr, uint32_t stag
             fr.queue = queue + (c->launches & 1u);
             fr.queue_next = queue + ((c->launches + 1u) & 1u);
         }
-        HIP_TRY(c, rtk_launch_render(c->dsc, c->cam, part, fr, n_bands, c->n_cus, stage_waves, unit_px_log2, c->stream));
+        HIP_TRY(c, rtk_launch_render(c->dsc, c->cam, part, fr, n_bands, c->n_cus, stage_waves, unit_px_log2, c->stream,
+                                     cams, n_frames));
         if (!clear) c->launches += 1u;     // only a launch that ran has zeroed the other counter
     }
+    return RT_OK;
+}
+
+// The staging ring of rt_render: one part (24 KiB) per wavefront a launch of the scene's kernel can
+// have resident on this device - on 256 CUs 8,192 wavefronts = 192 MiB for a scene without a box
+// tree, half of that for one with a tree.  Allocated at the first render and kept; grows when a later
+// scene needs more.
+static int ensure_stage(Ctx *c) {
+    const uint32_t need = rtk_resident_waves(c->n_cus, c->dsc.modes);
+    if (c->d_stage && c->stage_waves >= need) return RT_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    c->d_stage = nullptr; c->stage_waves = 0;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_stage), (size_t)need * DEV_STAGE_WAVE_BYTES));
+    c->stage_waves = need;
     return RT_OK;
 }
 
@@ -331,9 +370,45 @@ int rt_render(rt_ctx *ctx, const rt_params *p) {
     if (p->width != c->W || p->height != c->H)
         return fail(c, RT_E_BADARG, "rt_render: width/height differ from rt_begin_frame");
     HIP_TRY(c, hipSetDevice(c->device));
-    DevFrame fr{c->d_disc, c->d_sphere, c->d_screen, c->d_accum, c->d_ids, c->d_stage, c->d_segments,
+    if ((rc = ensure_stage(c)) != RT_OK) return rc;
+    DevFrame fr{c->d_disc, c->d_sphere, c->d_screen, c->accum(), c->ids(), c->d_stage, c->d_segments,
                 nullptr, nullptr, 0u};
     return enqueue_render(c, p, fr, c->stage_waves, c->d_queue, nullptr, 0);
+}
+
+int rt_render_frames(rt_ctx *ctx, const rt_params *p, const rt_camera *cameras, uint32_t n_frames) {
+    Ctx *c = C(ctx);
+    if (!c) return RT_E_BADARG;
+    int rc = check_render(c, p, "rt_render_frames");
+    if (rc != RT_OK) return rc;
+    if (!c->have_tables || !c->have_scene || !c->have_frame)
+        return fail(c, RT_E_STATE, "rt_render_frames: tables, scene and frames must be set first");
+    if (!cameras || n_frames == 0 || n_frames > c->n_frames)
+        return fail(c, RT_E_BADARG, "rt_render_frames: no cameras, or more of them than rt_begin_frames made frames");
+    if (p->width != c->W || p->height != c->H)
+        return fail(c, RT_E_BADARG, "rt_render_frames: width/height differ from rt_begin_frames");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if ((rc = ensure_stage(c)) != RT_OK) return rc;
+    if (rtk_has_frames_kernel(c->dsc.modes)) {
+        // one launch (per 512 samples) over the tiles of all frames; the cameras go to device memory first
+        // (the copy from the caller's pageable memory has left it when the call returns)
+        HIP_TRY(c, hipMemcpyAsync(c->d_cams, cameras, n_frames * sizeof(rt_camera), hipMemcpyHostToDevice, c->stream));
+        DevFrame fr{c->d_disc, c->d_sphere, c->d_screen, c->d_accum, c->d_ids, c->d_stage, c->d_segments,
+                    nullptr, nullptr, 0u};
+        return enqueue_render(c, p, fr, c->stage_waves, c->d_queue, nullptr, 0, c->d_cams, n_frames);
+    }
+    // scenes with long runs: their kernels take one frame per launch, and a frame of such a scene keeps a
+    // launch busy by itself
+    const rt_camera keep = c->cam;
+    const uint32_t keep_sel = c->sel;
+    for (uint32_t f = 0; f < n_frames && rc == RT_OK; ++f) {
+        c->cam = cameras[f]; c->sel = f;
+        DevFrame fr{c->d_disc, c->d_sphere, c->d_screen, c->accum(), c->ids(), c->d_stage, c->d_segments,
+                    nullptr, nullptr, 0u};
+        rc = enqueue_render(c, p, fr, c->stage_waves, c->d_queue, nullptr, 0);
+    }
+    c->cam = keep; c->sel = keep_sel;
+    return rc;
 }
 
 int rt_render_static(rt_ctx *ctx, const rt_params *p, void *accum_device, int32_t *ids_device,
@@ -360,7 +435,7 @@ int rt_pack(rt_ctx *ctx) {
     if (!c) return RT_E_BADARG;
     if (!c->have_frame) return fail(c, RT_E_STATE, "rt_pack: no frame");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, rtk_launch_pack(c->d_accum, c->d_packed, c->W * c->H, c->stream));
+    HIP_TRY(c, rtk_launch_pack(c->accum(), c->packed(), c->W * c->H, c->stream));
     return RT_OK;
 }
 
@@ -392,7 +467,7 @@ int rt_read_accum(rt_ctx *ctx, float *rgb, size_t n_px) {
     if (rc != RT_OK) return rc;
     std::vector<float4> tmp;
     try { tmp.resize(n_px); } catch (...) { return fail(c, RT_E_OOM, "rt_read_accum: out of host memory"); }
-    if ((rc = read_back(c, tmp.data(), c->d_accum, n_px * sizeof(float4))) != RT_OK) return rc;
+    if ((rc = read_back(c, tmp.data(), c->accum(), n_px * sizeof(float4))) != RT_OK) return rc;
     for (size_t k = 0; k < n_px; ++k) { rgb[3 * k] = tmp[k].x; rgb[3 * k + 1] = tmp[k].y; rgb[3 * k + 2] = tmp[k].z; }
     return RT_OK;
 }
@@ -403,7 +478,7 @@ int rt_read_sample_counts(rt_ctx *ctx, uint32_t *counts, size_t n_px) {
     if (rc != RT_OK) return rc;
     std::vector<float4> tmp;
     try { tmp.resize(n_px); } catch (...) { return fail(c, RT_E_OOM, "rt_read_sample_counts: out of host memory"); }
-    if ((rc = read_back(c, tmp.data(), c->d_accum, n_px * sizeof(float4))) != RT_OK) return rc;
+    if ((rc = read_back(c, tmp.data(), c->accum(), n_px * sizeof(float4))) != RT_OK) return rc;
     for (size_t k = 0; k < n_px; ++k) counts[k] = (uint32_t)tmp[k].w;
     return RT_OK;
 }
@@ -413,14 +488,14 @@ int rt_read_packed(rt_ctx *ctx, uint32_t *out, size_t n_px) {
     int rc = check_read(c, out, n_px, "rt_read_packed");
     if (rc != RT_OK) return rc;
     if ((rc = rt_pack(ctx)) != RT_OK) return rc;
-    return read_back(c, out, c->d_packed, n_px * sizeof(uint32_t));
+    return read_back(c, out, c->packed(), n_px * sizeof(uint32_t));
 }
 
 int rt_read_primary_ids(rt_ctx *ctx, int32_t *ids, size_t n_px) {
     Ctx *c = C(ctx);
     int rc = check_read(c, ids, n_px, "rt_read_primary_ids");
     if (rc != RT_OK) return rc;
-    return read_back(c, ids, c->d_ids, n_px * sizeof(int32_t));
+    return read_back(c, ids, c->ids(), n_px * sizeof(int32_t));
 }
 
 int rt_ray_count(rt_ctx *ctx, uint64_t *segments) {
@@ -452,10 +527,11 @@ int rtdbg_read_counters(rt_ctx *ctx, uint64_t out[8]) {
 int rt_device_buffers(rt_ctx *ctx, void **accum, void **packed, void **ids, void **stream) {
     Ctx *c = C(ctx);
     if (!c) return RT_E_BADARG;
-    if (!c->have_frame) return fail(c, RT_E_STATE, "rt_device_buffers: no frame");
-    if (accum) *accum = c->d_accum;
-    if (packed) *packed = c->d_packed;
-    if (ids) *ids = c->d_ids;
+    // (without a frame the buffers are null and only the stream is handed out: callers of
+    // rt_render_static need no frame but must be able to order their own work against the stream)
+    if (accum) *accum = c->have_frame ? c->accum() : nullptr;
+    if (packed) *packed = c->have_frame ? c->packed() : nullptr;
+    if (ids) *ids = c->have_frame ? c->ids() : nullptr;
     if (stream) *stream = c->stream;
     return RT_OK;
 }
@@ -473,7 +549,7 @@ int rt_export_packed_bands(rt_ctx *ctx, uint32_t *dst_device, size_t capacity_px
     if (n_bands == 0) return RT_OK;
     if (n_bands * RT_BAND_ROWS > 65535u) return fail(c, RT_E_BADARG, "rt_export_packed_bands: too many rows");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, rtk_launch_pack_bands(c->d_accum, dst_device, c->W, c->H, band_begin, band_stride, n_bands,
+    HIP_TRY(c, rtk_launch_pack_bands(c->accum(), dst_device, c->W, c->H, band_begin, band_stride, n_bands,
                                      c->stream));
     return RT_OK;
 }
@@ -494,6 +570,18 @@ int rt_gather_packed(rt_ctx *const *ctxs, uint32_t n_ctx, uint32_t *out, size_t 
     }
     // every block is padded to the band count of context 0, the largest
     const size_t block_px = (size_t)bands_of(H, 0, n_ctx) * RT_BAND_ROWS * W;
+    // development aid: RT_HIP_GATHER_STAGED=1 sends the blocks of contexts on the root's own GPU through
+    // the staging block and a peer copy as well (a peer copy within one device is valid), so that the
+    // path several GPUs take can be exercised on one
+    const char *staged_env = std::getenv("RT_HIP_GATHER_STAGED");
+    const bool force_staged = staged_env && staged_env[0] && staged_env[0] != '0';
+    // a failure on another context is reported where the caller looks for it
+    auto on_root = [&](Ctx *c, int rc) { if (c != root) root->err = c->err; return rc; };
+#define HIP_TRY_ON(ctx, call)                                                       \
+    do {                                                                            \
+        hipError_t e_ = (call);                                                     \
+        if (e_ != hipSuccess) return on_root((ctx), hip_fail((ctx), e_, #call));    \
+    } while (0)
     HIP_TRY(root, hipSetDevice(root->device));
     if (root->gather_px < block_px * n_ctx) {
         HIP_TRY(root, hipStreamSynchronize(root->stream));
@@ -504,35 +592,37 @@ int rt_gather_packed(rt_ctx *const *ctxs, uint32_t n_ctx, uint32_t *out, size_t 
     }
     for (uint32_t g = 0; g < n_ctx; ++g) {
         Ctx *c = C(ctxs[g]);
-        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY_ON(c, hipSetDevice(c->device));
         uint32_t *dst = root->d_gather + block_px * g;
-        if (c->device == root->device) {
+        // the previous gather's reader must be done with the gather buffer before anything writes it
+        if (c != root) HIP_TRY_ON(c, hipStreamWaitEvent(c->stream, root->ev_block, 0));
+        if (c->device == root->device && !(force_staged && c != root)) {
             // same GPU: quantise straight into the gather buffer
-            if (c != root) HIP_TRY(c, hipStreamWaitEvent(c->stream, root->ev_block, 0));
             int rc = rt_export_packed_bands(ctxs[g], dst, block_px, g, n_ctx);
-            if (rc != RT_OK) return rc;
+            if (rc != RT_OK) return on_root(c, rc);
         } else {
             if (c->block_px < block_px) {
-                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                HIP_TRY_ON(c, hipStreamSynchronize(c->stream));
                 if (c->d_block) (void)hipFree(c->d_block);
                 c->d_block = nullptr; c->block_px = 0;
-                HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_block), block_px * sizeof(uint32_t)));
+                HIP_TRY_ON(c, hipMalloc(reinterpret_cast<void **>(&c->d_block), block_px * sizeof(uint32_t)));
                 c->block_px = block_px;
             }
             int rc = rt_export_packed_bands(ctxs[g], c->d_block, block_px, g, n_ctx);
-            if (rc != RT_OK) return rc;
+            if (rc != RT_OK) return on_root(c, rc);
             // one copy per peer over its own link to the gathering GPU
-            HIP_TRY(c, hipMemcpyPeerAsync(dst, root->device, c->d_block, c->device, block_px * sizeof(uint32_t), c->stream));
+            HIP_TRY_ON(c, hipMemcpyPeerAsync(dst, root->device, c->d_block, c->device, block_px * sizeof(uint32_t), c->stream));
         }
-        if (c != root) HIP_TRY(c, hipEventRecord(c->ev_block, c->stream));
+        if (c != root) HIP_TRY_ON(c, hipEventRecord(c->ev_block, c->stream));
     }
+#undef HIP_TRY_ON
     HIP_TRY(root, hipSetDevice(root->device));
     for (uint32_t g = 1; g < n_ctx; ++g) HIP_TRY(root, hipStreamWaitEvent(root->stream, C(ctxs[g])->ev_block, 0));
-    HIP_TRY(root, rtk_launch_compose_bands(root->d_gather, root->d_packed, W, H, n_ctx, block_px, root->stream));
+    HIP_TRY(root, rtk_launch_compose_bands(root->d_gather, root->packed(), W, H, n_ctx, block_px, root->stream));
     // the next gather's writers wait for this one's reader (contexts that share the root's GPU write
     // into the gather buffer directly)
     HIP_TRY(root, hipEventRecord(root->ev_block, root->stream));
-    return read_back(root, out, root->d_packed, n_px * sizeof(uint32_t));
+    return read_back(root, out, root->packed(), n_px * sizeof(uint32_t));
 }
 
 int rt_check_arith(rt_ctx *ctx, uint64_t operands, uint32_t seed, uint64_t mismatches[2]) {
@@ -559,6 +649,23 @@ int rt_check_arith(rt_ctx *ctx, uint64_t operands, uint32_t seed, uint64_t misma
     mismatches[0] = host[0]; mismatches[1] = host[1];
     return RT_OK;
 }
+
+int rt_kernel_info(rt_ctx *ctx, uint32_t max_bounces, uint32_t *scan_modes, uint32_t *depth_budget) {
+    Ctx *c = C(ctx);
+    if (!c) return RT_E_BADARG;
+    if (!c->have_scene) return fail(c, RT_E_STATE, "rt_kernel_info: no scene");
+    if (max_bounces > RT_MAX_BOUNCES) return fail(c, RT_E_BADARG, "rt_kernel_info: max_bounces above RT_MAX_BOUNCES");
+    uint32_t modes = 0, depth = 0;
+    rtk_kernel_variant(c->dsc.modes, max_bounces, &modes, &depth);
+    if (scan_modes) *scan_modes = modes;
+    if (depth_budget) *depth_budget = depth;
+    return RT_OK;
+}
+
+#ifndef RT_BUILD_ID
+#define RT_BUILD_ID "unknown"
+#endif
+const char *rt_build_id(void) { return RT_BUILD_ID; }
 
 int rt_timer_start(rt_ctx *ctx) {
     Ctx *c = C(ctx);

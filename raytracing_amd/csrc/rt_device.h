@@ -76,7 +76,13 @@ struct DevScene {
     uint32_t cheap_ok;        // every sphere has finite |centre| <= 2^30 and 2^-30 <= |radius| <= 2^30: rays of
                               // moderate origin and length may take the short division and root sequences
 };
-#define DEV_SAMPLE_CHUNK 64u     // samples per pixel one launch renders at most
+// Samples per pixel one launch renders at most: what a ring slot holds for a work unit of one pixel.
+// A launch has a fixed cost of 0.5 to 0.8 ms (its waves end unevenly), so a frame takes as few launches
+// as it can: 256 samples of a 4K frame in one launch (units of two pixels) against four of 64 samples
+// (units of eight): 10,000 spheres 387.8 against 395.8 ms, a million triangles 177.7 against 185.9.
+#ifndef DEV_SAMPLE_CHUNK
+#define DEV_SAMPLE_CHUNK 512u
+#endif
 // Staging ring: every wavefront of a render launch keeps the colours of its unfinished work
 // units in a part of its own, DEV_STAGE_SLOTS units of at most 2^DEV_STAGE_ITEM_BITS (pixel,
 // sample) items, 12 bytes each.  The ring's size depends on the launch's grid, not on the frame.
@@ -121,9 +127,14 @@ struct DevFrame {
 
 // stage_waves: wavefronts the staging ring behind fr.stage has room for (the grid is cut to it);
 // unit_px_log2: pixels of a tile per work unit, or -1 to choose by launch size
+// cams (device memory, may be null), n_frames: one launch over n_frames frames of p.width x p.height, frame
+// f through cams[f] into frame f of fr.accum and fr.primary_ids (width*height elements apart); only scenes
+// for which rtk_has_frames_kernel(modes) holds.  With cams == null: one frame through `cam`.
 hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_params &p,
                              const DevFrame &fr, uint32_t n_bands, uint32_t n_cus, uint32_t stage_waves,
-                             int unit_px_log2, hipStream_t stream);
+                             int unit_px_log2, hipStream_t stream, const rt_camera *cams = nullptr,
+                             uint32_t n_frames = 1u);
+bool rtk_has_frames_kernel(uint32_t modes);
 // The per-GPU static scratch of rt_render_static (see rt_kernels.hip): device addresses of its
 // parts on `device`, which must be the current device the first time it is asked for.
 struct RtkStaticScratch {
@@ -134,8 +145,11 @@ struct RtkStaticScratch {
     uint32_t head_bytes;
 };
 hipError_t rtk_static_scratch(int device, RtkStaticScratch *out);
-// wavefronts a render launch puts on a device with n_cus compute units at most
-uint32_t rtk_resident_waves(uint32_t n_cus);
+// wavefronts a render launch of a scene with these scan modes (DevScene::modes) puts on a device with
+// n_cus compute units at most
+uint32_t rtk_resident_waves(uint32_t n_cus, uint32_t modes);
+// the instantiation render_tiles<scan_modes, depth_budget> a launch with this depth budget runs
+void rtk_kernel_variant(uint32_t modes, uint32_t max_bounces, uint32_t *scan_modes, uint32_t *depth_budget);
 hipError_t rtk_launch_pack_bands(const float4 *accum, uint32_t *out, uint32_t W, uint32_t H,
                                  uint32_t band_begin, uint32_t band_stride, uint32_t n_bands,
                                  hipStream_t stream);

@@ -32,6 +32,7 @@
 // vector register count anyway, 8 elsewhere (with 16 this rare step set it: 96 registers instead of 64)
 __host__ __device__ constexpr uint32_t sum_batch_of(int modes) { return (modes & 2) ? 16u : 8u; }
 static_assert(DEV_STAGE_SLOTS == 4u, "UnitRing and the slot arithmetic assume four units in flight per wave");
+static_assert(DEV_SAMPLE_CHUNK <= (1u << DEV_STAGE_ITEM_BITS), "the samples of a launch, for one pixel, must fit a ring slot");
 #ifndef RTK_TREE_WAVES
 #define RTK_TREE_WAVES 8
 #endif
@@ -248,7 +249,8 @@ struct TreeTable {
 
 // The work units a wave has in flight (see render_tiles): column | row << 16 of the unit's first
 // pixel (row counted from the bottom), and the number of items not finished yet (0 = slot free).
-struct UnitRing { uint32_t xy[4], left[4]; };
+// `fr`: the frame of a launch over several frames the unit belongs to (render_tiles<.., FRAMES = true>).
+struct UnitRing { uint32_t xy[4], left[4], fr[4]; };
 
 // MODES: bit 0 = the scene has RUN_FLAT runs, bit 1 = it has RUN_TREE runs; the
 // kernel is compiled once per combination so that scenes without a tree do not
@@ -276,7 +278,8 @@ static_assert(2u * sizeof(Lds<2, (int)DEV_STACK_SHALLOW>) <= 160u * 1024u && 2u 
 struct Ray { V3 o, d; };
 
 // Camera::get_ray, src/camera/mod.rs:75-79
-__device__ __forceinline__ Ray get_ray(const RT_CONST_AS rt_camera &c, float s, float t, float da, float db) {
+template <class Cam>   // the camera in the kernel's arguments (scalar loads), or one of a launch's cameras in device memory
+__device__ __forceinline__ Ray get_ray(const Cam &c, float s, float t, float da, float db) {
     V3 origin = mk(c.origin[0], c.origin[1], c.origin[2]);
     V3 llc = mk(c.lower_left_corner[0], c.lower_left_corner[1], c.lower_left_corner[2]);
     V3 hor = mk(c.horizontal[0], c.horizontal[1], c.horizontal[2]);
@@ -1145,7 +1148,7 @@ __device__ __forceinline__ V3 sky(V3 ud, bool gamma) {
 // calculate_some_pxls + ray_colour, src/raytracer.rs:232-271 and :68-92.
 //
 // The launch is a fixed number of resident workgroups; every wavefront on its own takes work
-// units from one global queue until the queue is empty.  A unit is 2 to 64 pixels of an 8x8 tile
+// units from one global queue until the queue is empty.  A unit is 1 to 64 pixels of an 8x8 tile
 // (part of a row, or whole rows; chosen per launch, see rtk_launch_render) x all samples of the
 // launch; its work items
 // (pixel, sample), sample-major, are handed to the wave's lanes one at a time: a lane whose
@@ -1162,9 +1165,19 @@ __device__ __forceinline__ V3 sky(V3 ud, bool gamma) {
 constexpr uint32_t ITEM_BITS = DEV_STAGE_ITEM_BITS;   // item index inside a unit: pixels of the unit x samples of the launch <= 512
 
 // the arguments of render_tiles as they lie in the kernel's argument block
-struct KernArgs { DevScene dsc; rt_camera cam; rt_params p; DevFrame fr; uint32_t n_bands, unit_px_log2, stretch_unit, fetch_min; };
+// (cams, n_frames: a launch over several frames of one size, frame f seen through cams[f], its per-pixel
+// buffers frame f of fr.accum / fr.primary_ids - only the kernels compiled with FRAMES read them)
+struct KernArgs {
+    DevScene dsc; rt_camera cam; rt_params p; DevFrame fr; uint32_t n_bands, unit_px_log2, stretch_unit, fetch_min;
+    const rt_camera *cams; uint32_t n_frames;
+};
 
-template <int MODES, int DEPTH>
+// FRAMES: the launch covers n_frames frames of one size with a camera each (the reference renders ten
+// in a row, moving the camera in between, src/raytracer.rs:32,165,190): the queue's units run over the
+// tiles of all of them, so that frames too small to fill the chip - the reference's own 600 x 337 at one
+// sample is 3,192 tiles for 8,192 wavefronts - share a launch instead of paying its start and its
+// uneven end once each.
+template <int MODES, int DEPTH, bool FRAMES = false>
 // Two 8-wave workgroups per CU: four waves per SIMD, at most 128 VGPRs each (some per-item
 // state is spilled around the walk).  Measured alternatives on the 10,000-sphere frame: three
 // waves per SIMD without spills (one 12-wave workgroup per CU) -14 %, 4-wave workgroups with
@@ -1216,7 +1229,7 @@ void render_tiles(KernArgs by_value) {
     StagedRgb *const stage = args0->fr.stage + ((size_t)(blockIdx.x * waves_of(MODES) + wave) << (ITEM_BITS + 2u));
 
     // units of this launch: tile by tile along the band, the parts of a tile one after the other
-    const uint32_t unit_px = 1u << unit_px_log2;                  // 2 .. 64 pixels: part of a tile row, or whole rows
+    const uint32_t unit_px = 1u << unit_px_log2;                  // 1 .. 64 pixels: part of a tile row, or whole rows
     const uint32_t unit_cols = unit_px < 8u ? unit_px : 8u, unit_rows = unit_px < 8u ? 1u : unit_px >> 3;
 
     // Per-lane state that lives across the scan is kept small (registers are what limits the
@@ -1242,7 +1255,7 @@ void render_tiles(KernArgs by_value) {
     // units the wave may still take from the stretch it was given last (wave-uniform)
     uint32_t stretch_next = 0u, stretch_end = 0u, asked = 1u;   // asked: units of the request on the way
 
-    struct Where { uint32_t i, j, s; };      // column, row from the bottom, sample
+    struct Where { uint32_t i, j, s, f; };      // column, row from the bottom, sample, frame of the launch
     auto where = [&](uint32_t it) {
         const uint32_t slot = it >> ITEM_BITS, q = it & ((1u << ITEM_BITS) - 1u);
         const uint32_t xy = ring.xy[slot];
@@ -1250,8 +1263,10 @@ void render_tiles(KernArgs by_value) {
         w.i = (xy & 0xffffu) + (q & (unit_cols - 1u));
         w.j = (xy >> 16) + ((q >> 3) & (unit_rows - 1u));
         w.s = sample_begin + (q >> unit_px_log2);
+        w.f = FRAMES ? ring.fr[slot] : 0u;
         return w;
     };
+    const size_t frame_px = FRAMES ? (size_t)W * H : 0u;    // pixels between a frame's buffers and the next one's
     auto path_key_at = [&](const Where &w, uint32_t seed) { return mix32((w.j * W + w.i) ^ mix32(w.s ^ (seed * GOLDEN32))); };
 
     auto start_sample = [&](const Where &w) {
@@ -1271,7 +1286,8 @@ void render_tiles(KernArgs by_value) {
         float u, v;
         if (cheap_uv) { u = div_refined((float)w.i + ox, w1, inv_w1); v = div_refined((float)w.j + oy, h1, inv_h1); }
         else { u = ((float)w.i + ox) / w1; v = ((float)w.j + oy) / h1; }
-        ray = get_ray(k->cam, u, v, la, lb);
+        if (FRAMES) ray = get_ray(k->cams[w.f], u, v, la, lb);
+        else ray = get_ray(k->cam, u, v, la, lb);
         path_counter = path_key_at(w, k->p.seed);
         // BlueNoise::get_screenspace, src/denoising/mod.rs:19-23: fixed per pixel, kept for the path
         sp_bn = k->fr.tbl_screen[128u * (w.i % 128u) + (w.j % 128u)];
@@ -1285,6 +1301,15 @@ void render_tiles(KernArgs by_value) {
     // for a new unit, or at the end.  One unit alone keeps as many lanes busy as it has pixels (8 of
     // 64 at 64 samples per launch) for as many dependent additions as the launch has samples.
     uint32_t unsummed = 0u;
+    // (RTK_NO_STAGE, a measurement build: colours are neither staged nor read back, the sums stay zero -
+    // what the staging traffic costs is the difference in time)
+    auto staged = [&](uint32_t it) {
+#ifdef RTK_NO_STAGE
+        StagedRgb c; c.r = c.g = c.b = __uint_as_float(it & 0u); return c;
+#else
+        return stage[it];
+#endif
+    };
     auto finish_units = [&](uint32_t slots) {
         const RT_CONST_AS KernArgs *k = args();
         float4 *const accum = k->fr.accum;
@@ -1305,7 +1330,8 @@ void render_tiles(KernArgs by_value) {
             const uint32_t xy = ring.xy[slot & 3u];
             const uint32_t pi = (xy & 0xffffu) + (q & 7u), pj = (xy >> 16) + (q >> 3);
             if (u < n_slots && pi < W && pj < H) {
-                const size_t pix_out = (size_t)(H - 1u - pj) * W + pi;   // src/raytracer.rs:265
+                size_t pix_out = (size_t)(H - 1u - pj) * W + pi;   // src/raytracer.rs:265
+                if (FRAMES) pix_out += frame_px * ring.fr[slot & 3u];
                 float4 acc = accum[pix_out];
                 V3 px = mk(acc.x, acc.y, acc.z);
                 // with a depth budget of 0 every sample is black and nothing was traced
@@ -1317,12 +1343,12 @@ void render_tiles(KernArgs by_value) {
                 for (; n + sum_batch_of(MODES) <= n_add; n += sum_batch_of(MODES)) {
                     StagedRgb c[sum_batch_of(MODES)];
 #pragma unroll
-                    for (uint32_t m = 0; m < sum_batch_of(MODES); ++m) c[m] = stage[item0 + ((n + m) << unit_px_log2)];
+                    for (uint32_t m = 0; m < sum_batch_of(MODES); ++m) c[m] = staged(item0 + ((n + m) << unit_px_log2));
 #pragma unroll
                     for (uint32_t m = 0; m < sum_batch_of(MODES); ++m) px = px + mk(c[m].r, c[m].g, c[m].b);
                 }
                 for (; n < n_add; ++n) {
-                    const StagedRgb c = stage[item0 + (n << unit_px_log2)];
+                    const StagedRgb c = staged(item0 + (n << unit_px_log2));
                     px = px + mk(c.r, c.g, c.b);
                 }
                 accum[pix_out] = make_float4(px.x, px.y, px.z, acc.w + (float)sample_count);
@@ -1345,7 +1371,7 @@ void render_tiles(KernArgs by_value) {
                 const RT_CONST_AS KernArgs *k = args();
                 const uint32_t tiles_x = (W + TILE - 1u) / TILE;
                 const uint32_t sub_log2 = 6u - unit_px_log2;                  // units per tile, log2
-                const uint32_t n_units = (tiles_x * k->n_bands) << sub_log2;
+                const uint32_t n_units = (tiles_x * k->n_bands * (FRAMES ? k->n_frames : 1u)) << sub_log2;
                 const uint32_t sample_count = k->p.sample_count;
                 uint32_t u;
                 // (only the kernels with a tree: a scene without one has short launches, and the
@@ -1371,14 +1397,17 @@ void render_tiles(KernArgs by_value) {
                     else if (lane == 0u) unit_ahead = grid_waves + atomicAdd(k->fr.queue, asked);
                 }
                 const uint32_t t = u >> sub_log2, sub = u & ((1u << sub_log2) - 1u);
-                const uint32_t by = t / tiles_x, tx = t - by * tiles_x;
+                uint32_t by = t / tiles_x;
+                const uint32_t tx = t - by * tiles_x;
+                uint32_t frame = 0u;
+                if (FRAMES) { frame = by / k->n_bands; by -= frame * k->n_bands; }   // frame after frame, each band by band
                 const uint32_t band = k->p.band_begin + by * k->p.band_stride;
                 const uint32_t first = sub << unit_px_log2;                 // the unit's first pixel of the tile, row-major
                 const uint32_t x0 = tx * TILE + (first & 7u), y0 = band * TILE + (first >> 3);
                 const uint32_t vw = x0 >= W ? 0u : (W - x0 < unit_cols ? W - x0 : unit_cols);
                 const uint32_t vh = y0 >= H ? 0u : (H - y0 < unit_rows ? H - y0 : unit_rows);
                 const uint32_t left = max_bounces > 0u ? vw * vh * sample_count : 0u;
-                if (lane == 0u) { ring.xy[slot] = x0 | (y0 << 16); ring.left[slot] = left; }
+                if (lane == 0u) { ring.xy[slot] = x0 | (y0 << 16); ring.left[slot] = left; if (FRAMES) ring.fr[slot] = frame; }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 cur_slot = slot; cur_next = 0u; cur_n = max_bounces > 0u ? sample_count << unit_px_log2 : 0u;
                 if (left == 0u) { unsummed |= 1u << slot; continue; }
@@ -1432,7 +1461,7 @@ void render_tiles(KernArgs by_value) {
             const uint32_t n_stack = max_bounces - depth_left;   // hits of this path so far
             if (n_stack == 0u) {
                 const Where at = where(item);
-                if (at.s == 0u) ks->fr.primary_ids[(size_t)(H - 1u - at.j) * W + at.i] = h.id;   // src/raytracer.rs:265
+                if (at.s == 0u) ks->fr.primary_ids[frame_px * at.f + (size_t)(H - 1u - at.j) * W + at.i] = h.id;   // src/raytracer.rs:265
             }
             // unit_vector(direction): the sky (src/raytracer.rs:82), Metal and Dielectric all start
             // from it; computed once for the wave instead of once per branch
@@ -1497,7 +1526,11 @@ void render_tiles(KernArgs by_value) {
                 k = k >= 4u ? k - 4u : 0u;
             }
             StagedRgb out; out.r = c.x; out.g = c.y; out.b = c.z;
+#ifdef RTK_NO_STAGE
+            asm volatile("" ::"v"(out.r), "v"(out.g), "v"(out.b));
+#else
             stage[item] = out;
+#endif
         }
         // (at most four different units in a wave)
         unsigned long long dm = refill ? __builtin_amdgcn_ballot_w64(parked) : 0ull;
@@ -1680,6 +1713,7 @@ static const void *render_kernel(uint32_t which) {
     case 3: return (const void *)rtk::render_tiles<3, DEV_STACK_SHALLOW>;
     case 6: return (const void *)rtk::render_tiles<2, RT_MAX_BOUNCES>;
     case 7: return (const void *)rtk::render_tiles<3, RT_MAX_BOUNCES>;
+    case 8: return (const void *)rtk::render_tiles<0, RT_MAX_BOUNCES, true>;    // several frames per launch
     default: return nullptr;
     }
 }
@@ -1689,9 +1723,9 @@ static uint32_t kernel_index(uint32_t modes, uint32_t max_bounces) {
 // workgroups of a render kernel that fit one CU, asked once per process (the same on every GPU of a node)
 static uint32_t blocks_per_cu(uint32_t which) {
     static std::once_flag once;
-    static int fit[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    static int fit[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     std::call_once(once, [] {
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < 9; ++m) {
             const void *kernel = render_kernel((uint32_t)m);
             if (!kernel) continue;
             int n = 0;
@@ -1700,40 +1734,47 @@ static uint32_t blocks_per_cu(uint32_t which) {
             fit[m] = n;
         }
     });
-    return (uint32_t)fit[which & 7u];
+    return (uint32_t)fit[which < 9u ? which : 0u];
 }
-uint32_t rtk_resident_waves(uint32_t n_cus) {
-    (void)blocks_per_cu(0u);   // asked here, when a context is made, so that no launch has to
-    return n_cus * 4u * (RTK_OCC > RTK_OCC0 ? RTK_OCC : RTK_OCC0);
+uint32_t rtk_resident_waves(uint32_t n_cus, uint32_t modes) {
+    (void)blocks_per_cu(0u);   // asked here, before the first launch, so that no launch has to
+    return n_cus * 4u * (uint32_t)rtk::occ_of((int)(modes & 3u));
 }
+void rtk_kernel_variant(uint32_t modes, uint32_t max_bounces, uint32_t *scan_modes, uint32_t *depth_budget) {
+    *scan_modes = modes & 3u;
+    *depth_budget = ((modes & 2u) && max_bounces <= DEV_STACK_SHALLOW) ? DEV_STACK_SHALLOW : RT_MAX_BOUNCES;
+}
+bool rtk_has_frames_kernel(uint32_t modes) { return (modes & 3u) == 0u; }
 hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_params &p,
                              const DevFrame &fr, uint32_t n_bands, uint32_t n_cus, uint32_t stage_waves,
-                             int unit_px_log2, hipStream_t stream) {
+                             int unit_px_log2, hipStream_t stream, const rt_camera *cams, uint32_t n_frames) {
     const uint32_t waves = (uint32_t)rtk::waves_of((int)(sc.modes & 3u));
     const uint32_t tiles_x = (p.width + rtk::TILE - 1u) / rtk::TILE;
-    const uint64_t n_tiles = (uint64_t)tiles_x * n_bands;
+    const bool frames = cams != nullptr;
+    if (frames && (n_frames == 0u || !rtk_has_frames_kernel(sc.modes))) return hipErrorInvalidValue;
+    const uint64_t n_tiles = (uint64_t)tiles_x * n_bands * (frames ? n_frames : 1u);
     // workgroups the chip holds at once (what the kernel is written for, and no more than the runtime
     // says fit a CU: a workgroup that is not resident would start its first unit when another one ends),
     // and the staging ring has room for
-    const uint64_t resident = std::min<uint64_t>((uint64_t)n_cus * std::min<uint32_t>(4u * rtk::occ_of((int)(sc.modes & 3u)) / waves, blocks_per_cu(kernel_index(sc.modes, p.max_bounces))),
+    const uint64_t resident = std::min<uint64_t>((uint64_t)n_cus * std::min<uint32_t>(4u * rtk::occ_of((int)(sc.modes & 3u)) / waves, blocks_per_cu(frames ? 8u : kernel_index(sc.modes, p.max_bounces))),
                                                  stage_waves / waves);
     if (p.sample_count > DEV_SAMPLE_CHUNK || p.width > 65536u || p.height > 65536u || resident == 0u) return hipErrorInvalidValue;
     const uint64_t max_items = 1ull << DEV_STAGE_ITEM_BITS;    // a unit's colours must fit one ring slot
-    // Pixels of a tile per work unit (part of a row, or whole rows): the fewest that still give a
-    // unit 512 work items (eight per lane).  Measured on 4K frames at 64 samples per launch, whole
+    // Pixels of a tile per work unit (one pixel, part of a row, or whole rows): as many as a ring slot's
+    // 512 work items (eight per lane) allow with the samples of this launch, 64 at most.  Measured on 4K frames at 64 samples per launch, whole
     // frame / one eighth of the bands, 10,000 spheres: 4 pixels 135.2 / 17.4 ms, 8 pixels 132.2 /
     // 17.8, 16 pixels 132.1 / 19.1, 32 pixels 135.3 / 21.9, 64 pixels 139.1 / 26.5; the
     // million-triangle scene 69.8 / 9.2 ms with 4, 64.9 / 9.4 with 8, 75.9 / 22.1 with 64.
-    if (unit_px_log2 < 1 || unit_px_log2 > 6) {
-        unit_px_log2 = 3;
-        while (unit_px_log2 < 6 && ((uint64_t)p.sample_count << (unit_px_log2 + 1)) <= max_items) ++unit_px_log2;
+    if (unit_px_log2 < 0 || unit_px_log2 > 6) {
+        unit_px_log2 = 6;
+        while (unit_px_log2 > 0 && ((uint64_t)p.sample_count << unit_px_log2) > max_items) --unit_px_log2;
         // a small launch (one GPU's share of a frame): half as long units, so that a wave still
         // gets a few dozen of them.  Scenes without a tree have short segments and feel the cost of
         // a unit more (default scene at 64 samples, 256- against 512-item units: whole 1080p frame
         // 6.1 / 4.4 ms, half of its bands 3.2 / 2.5, a quarter 1.7 / 1.4, an eighth 1.02 / 0.98), so
         // there units are halved only below three per wave.
         const uint64_t want = (sc.modes & 2u) ? 48u : 3u;
-        if ((n_tiles << (6 - unit_px_log2)) < want * resident * waves && ((uint64_t)p.sample_count << unit_px_log2) >= 512u)
+        if (unit_px_log2 > 0 && (n_tiles << (6 - unit_px_log2)) < want * resident * waves && ((uint64_t)p.sample_count << unit_px_log2) >= 512u)
             --unit_px_log2;
     }
     if (((uint64_t)p.sample_count << unit_px_log2) > max_items) return hipErrorInvalidValue;
@@ -1753,9 +1794,9 @@ hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_
     // idle lanes a wave waits for before it hands out new work items
     const uint32_t fetch_min = (sc.modes & 3u) == 0u ? RTK_FETCH_MIN0
                                : ((sc.modes & 2u) && sc.lds_kind == DEV_TRI) ? RTK_FETCH_MIN_TRI : RTK_FETCH_MIN;
-    rtk::KernArgs ka{sc, cam, p, fr, n_bands, r, (uint32_t)stretch_unit, fetch_min};
+    rtk::KernArgs ka{sc, cam, p, fr, n_bands, r, (uint32_t)stretch_unit, fetch_min, cams, frames ? n_frames : 1u};
     if (p.max_bounces > RT_MAX_BOUNCES) return hipErrorInvalidValue;
-    const uint32_t which = kernel_index(sc.modes, p.max_bounces);
+    const uint32_t which = frames ? 8u : kernel_index(sc.modes, p.max_bounces);
     if (which >= 4u) {
         // the deep material stack leaves less room for the tree's top levels
         ka.dsc.lds_level = sc.lds_deep_level; ka.dsc.lds_first = sc.lds_deep_first; ka.dsc.lds_count = sc.lds_deep_count;
@@ -1767,6 +1808,7 @@ hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_
     case 2: hipLaunchKernelGGL((rtk::render_tiles<2, DEV_STACK_SHALLOW>), grid, block, 0, stream, ka); break;
     case 3: hipLaunchKernelGGL((rtk::render_tiles<3, DEV_STACK_SHALLOW>), grid, block, 0, stream, ka); break;
     case 6: hipLaunchKernelGGL((rtk::render_tiles<2, RT_MAX_BOUNCES>), grid, block, 0, stream, ka); break;
+    case 8: hipLaunchKernelGGL((rtk::render_tiles<0, RT_MAX_BOUNCES, true>), grid, block, 0, stream, ka); break;
     default: hipLaunchKernelGGL((rtk::render_tiles<3, RT_MAX_BOUNCES>), grid, block, 0, stream, ka); break;
     }
     return hipGetLastError();

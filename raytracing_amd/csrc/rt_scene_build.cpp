@@ -304,18 +304,11 @@ int build_host_scene(const rt_scene *s, bool use_tree, HostScene &sc, std::strin
 
     const double LEAF_EPS_SPHERE = 1.0 / 65536.0;   // proven bound of the kernel's test, see cull_pair
 
-    // A scene that gets a tree anyway gives its middling sphere runs (DEV_CULL_MIN_RUN and more) a
-    // tree as well: the kernel for scenes with both kinds of long runs is the one that does not fit
-    // the vector register file without spills, and a small tree costs a ray no more than the
-    // rejection scan of the whole run.
-    uint32_t sphere_tree_min = DEV_TREE_MIN_RUN;
-    for (uint32_t id = 0; id < n && use_tree;) {
-        uint32_t end = id;
-        while (end < n && list[end].kind == list[id].kind) ++end;
-        if ((list[id].kind == DEV_SPHERE || list[id].kind == DEV_TRI) && end - id >= DEV_TREE_MIN_RUN)
-            sphere_tree_min = DEV_CULL_MIN_RUN;
-        id = end;
-    }
+    // Sphere runs of DEV_CULL_MIN_RUN and more get a tree.  (The list-order rejection scan, RUN_FLAT, is
+    // kept for measurements - RT_HIP_FLAT_SCAN=1 - because it does the reference's work per segment;
+    // its kernels are the ones that do not fit the register file without spills, and from 32 spheres
+    // on a small tree costs a ray less than the rejection scan of the whole run.)
+    const uint32_t sphere_tree_min = DEV_CULL_MIN_RUN;
 
     for (uint32_t id = 0; id < n;) {
         const int kind = list[id].kind;

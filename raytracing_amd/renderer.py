@@ -114,8 +114,23 @@ class Renderer:
         self._check(self._lib.rt_begin_frame(self._ctx, width, height))
         self.width, self.height = width, height
 
+    def begin_frames(self, width, height, n_frames):
+        """rt_begin_frames: per-pixel buffers for n_frames frames of one size, all zeroed"""
+        self._check(self._lib.rt_begin_frames(self._ctx, width, height, n_frames))
+        self.width, self.height = width, height
+
+    def select_frame(self, frame):
+        """rt_select_frame: the frame render() and the read_* calls work on"""
+        self._check(self._lib.rt_select_frame(self._ctx, frame))
+
     def render(self, params):
         self._check(self._lib.rt_render(self._ctx, C.byref(params)))
+
+    def render_frames(self, params, cameras):
+        """rt_render_frames: frames 0..len(cameras)-1 at once, frame f through cameras[f]"""
+        structs = [c.struct if isinstance(c, Camera) else c for c in cameras]
+        arr = (_lib.rt_camera * len(structs))(*structs)
+        self._check(self._lib.rt_render_frames(self._ctx, C.byref(params), arr, len(structs)))
 
     def render_static(self, params, accum_ptr, ids_ptr, segments_ptr=None):
         """rt_render_static: render into caller-owned device buffers (raw device addresses),
@@ -134,6 +149,12 @@ class Renderer:
         bad = (C.c_uint64 * 2)()
         self._check(self._lib.rt_check_arith(self._ctx, operands, seed, bad))
         return int(bad[0]), int(bad[1])
+
+    def kernel_variant(self, max_bounces=10):
+        """rt_kernel_info: the render kernel a launch with this depth budget runs for the uploaded scene"""
+        modes, depth = C.c_uint32(), C.c_uint32()
+        self._check(self._lib.rt_kernel_info(self._ctx, max_bounces, C.byref(modes), C.byref(depth)))
+        return "render_tiles<%d, %d>" % (modes.value, depth.value)
 
     def timer_start(self):
         self._check(self._lib.rt_timer_start(self._ctx))

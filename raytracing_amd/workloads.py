@@ -3,16 +3,18 @@ a PCG32 stream with a fixed seed so every machine builds the same scene.
 
 c1  default scene of the reference, 600x337, 1 spp, aperture 0
 c2  the same scene with aperture 0.1, 1920x1080, 64 spp
-c3  default scene + a procedural triangle mesh (UV sphere), 1920x1080, 256 spp
+c3  default scene + a triangle mesh read from data/uv_sphere.obj (a UV sphere), 1920x1080, 256 spp
 c4  10,000 random spheres on a ground plane, 3840x2160, 256 spp
 c5  1024x512 displaced triangle grid (~1.05 M triangles) + default scene, 3840x2160, 1024 spp
 """
 import math
+import os
 
 import numpy as np
 
 from .scene import (Camera, Scene, Sphere, Triangle, Lambertian, flat_scene_from_arrays, image_height)
 from . import _lib
+from .obj import load_obj, write_obj
 
 
 class Pcg32:
@@ -103,12 +105,32 @@ def uv_sphere_mesh(center=(1.3, 0.3, 0.6), radius=0.3, n_lat=16, n_lon=32):
     return tris
 
 
+MESH_OBJ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "uv_sphere.obj")
+
+
+def write_mesh_obj(path=MESH_OBJ):
+    """uv_sphere_mesh() as a Wavefront .obj: vertices as binary32 values (nine significant digits,
+    which read back exactly), shared between the triangles that meet in them; faces in list order"""
+    index, verts, faces = {}, [], []
+    for tri in uv_sphere_mesh():
+        face = []
+        for v in tri:
+            key = tuple(float(np.float32(c)) for c in v)
+            if key not in index:
+                index[key] = len(verts)
+                verts.append(key)
+            face.append(index[key])
+        faces.append(tuple(face))
+    write_obj(path, verts, faces)
+    return len(verts), len(faces)
+
+
 def mesh_scene():
-    """c3: the default list followed by the mesh triangles (Lambertian 0.2,0.25,0.6)"""
+    """c3: the default list followed by the triangles of data/uv_sphere.obj (the 960-triangle UV sphere
+    of uv_sphere_mesh(), written by write_mesh_obj), Lambertian (0.2, 0.25, 0.6): the mesh comes in
+    through the .obj reader like any other, in file order"""
     scene = Scene.get_scene()
-    mat = Lambertian((0.2, 0.25, 0.6))
-    for a, b, c in uv_sphere_mesh():
-        scene.add(Triangle(a, b, c, mat))
+    load_obj(MESH_OBJ, scene, Lambertian((0.2, 0.25, 0.6)))
     return scene.flatten()
 
 
@@ -156,10 +178,18 @@ def workload(name):
     """-> dict(flat, camera, width, height, spp, description)"""
     name = name.lower()
     if name == "c1":
+        # the reference's own run: NUM_FRAMES_TO_RENDER = 10 frames, the camera one dolly step further
+        # after each (src/raytracer.rs:32,165-168,190; Scene::move_cam, src/scene/mod.rs:78-83)
         w = 600
-        return dict(flat=Scene.get_scene().flatten(), camera=default_camera(0.0, 1), width=w,
+        keep = Scene.COUNTER
+        cams = []
+        for f in range(10):
+            Scene.COUNTER = f
+            cams.append(default_camera(0.0, 1))
+        Scene.COUNTER = keep
+        return dict(flat=Scene.get_scene().flatten(), camera=cams[0], cameras=cams, width=w,
                     height=image_height(w), spp=1,
-                    description="reference default scene (8 primitives), 600x337, 1 spp")
+                    description="reference default scene (8 primitives), 600x337, 1 spp, its 10 frames")
     if name == "c2":
         return dict(flat=Scene.get_scene().flatten(), camera=default_camera(0.1, 64), width=1920,
                     height=image_height(1920), spp=64,

@@ -24,7 +24,9 @@ POISON = 0.05      # share of scenes that get non-finite or huge coordinates
 
 
 def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
+    arg = sys.argv[1] if len(sys.argv) > 1 else "30"
+    n_scenes = int(arg[:-1]) if arg.endswith("n") else None      # a budget of scenes (`150n`) instead of seconds
+    budget = float("inf") if n_scenes is not None else float(arg)
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     global POISON
     POISON = float(sys.argv[3]) if len(sys.argv) > 3 else 0.05
@@ -36,7 +38,8 @@ def main():
     k = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # number of the first scene (to repeat one scene of a run)
     bad = 0
     rays = 0
-    while time.time() - t0 < budget:
+    k_end = None if n_scenes is None else k + n_scenes
+    while time.time() - t0 < budget and (k_end is None or k < k_end):
         rng = np.random.default_rng(seed0 + k)
         flat, cam = scene(rng)
         notes = perturb(rng, flat, cam, POISON)

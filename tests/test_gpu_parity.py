@@ -107,8 +107,9 @@ def test_progressive_chunks_equal_one_shot(renderer, oracle, tables):
 
 
 def test_sample_ranges_longer_than_one_launch(renderer, oracle, tables):
-    """rt_render cuts a sample range into launches of at most 64 samples; 150 samples in one
-    call, in 70 + 80, and on the oracle are the same sums"""
+    """a launch takes up to 512 samples per pixel (its work units then are single pixels) and
+    rt_render cuts a longer range into several; 150 samples in one call (one launch, units of two
+    pixels) and in 70 + 80, and 600 samples (launches of 512 and 88) are the oracle's sums"""
     flat = Scene.get_scene().flatten()
     cam = Scene.get_camera(aperture=0.1)
     one = render_gpu(renderer, flat, cam, [make_params(40, 24, spp=150)])
@@ -116,11 +117,88 @@ def test_sample_ranges_longer_than_one_launch(renderer, oracle, tables):
                                            make_params(40, 24, spp=150, sample_begin=70, sample_count=80)])
     assert np.array_equal(_bits(one[0]), _bits(two[0])) and one[3] == two[3]
     assert_same(one, render_oracle(oracle, tables, flat, cam, [make_params(40, 24, spp=150)]), oracle)
+    long = render_gpu(renderer, flat, cam, [make_params(21, 13, spp=600)])
+    assert_same(long, render_oracle(oracle, tables, flat, cam, [make_params(21, 13, spp=600)]), oracle)
 
 
-@pytest.mark.parametrize("unit_px", [2, 4, 8, 16, 32, 64])
+def _frames_on_gpu(renderer, flat, cams, calls):
+    """rt_begin_frames + rt_render_frames (one call per entry of `calls`), then every frame's outputs"""
+    renderer.set_scene(flat)
+    renderer.begin_frames(calls[0].width, calls[0].height, len(cams))
+    for p in calls:
+        renderer.render_frames(p, cams)
+    out = []
+    for f in range(len(cams)):
+        renderer.select_frame(f)
+        out.append((renderer.read_accum(), renderer.read_primary_ids(), renderer.read_packed(),
+                    renderer.read_sample_counts()))
+    return out, renderer.ray_count()
+
+
+@pytest.mark.parametrize("w,h,spp,n_frames", [(600, 337, 1, 10), (61, 43, 3, 4), (120, 67, 70, 2)])
+def test_several_frames_in_one_launch(renderer, oracle, tables, w, h, spp, n_frames):
+    """rt_render_frames: the reference's run of ten frames (src/raytracer.rs:32,165; the camera one dolly
+    step further per frame, src/scene/mod.rs:78-83) in ONE launch at its own size and sample count, and
+    smaller cases with partial tiles and units of a few pixels: every frame's sums, ids, packed pixels
+    and sample counts are the oracle's for that frame's camera, the segment count is the total"""
+    flat = Scene.get_scene().flatten()
+    cams = [oracle.scene_camera(f, 0.1 if spp > 1 else 0.0) for f in range(n_frames)]
+    p = make_params(w, h, spp=spp)
+    got, seg = _frames_on_gpu(renderer, flat, cams, [p])
+    total = 0
+    for f, cam in enumerate(cams):
+        acc, ids, s = oracle.render(flat, cam, tables, p, threads=8)
+        total += s
+        assert np.array_equal(_bits(got[f][0]), _bits(np.ascontiguousarray(acc[..., :3]))), f
+        assert np.array_equal(got[f][1], ids) and np.array_equal(got[f][2], oracle.pack(acc)), f
+        assert np.array_equal(got[f][3], acc[..., 3].astype(np.uint32)), f
+    assert seg == total
+
+
+def test_frames_in_one_launch_equal_frames_one_by_one(renderer, oracle, tables):
+    """the same through the library alone: progressive sample ranges and a band share rendered for five
+    frames at once equal rt_select_frame + rt_set_camera + rt_render per frame; a scene with a box tree
+    (its frames are rendered one after the other inside the call) equals the oracle"""
+    flat = Scene.get_scene().flatten()
+    cams = [oracle.scene_camera(3 * f, 0.1) for f in range(5)]
+    w, h = 200, 112
+    calls = [make_params(w, h, spp=5, sample_begin=0, sample_count=2, band_begin=1, band_stride=2),
+             make_params(w, h, spp=5, sample_begin=2, sample_count=3, band_begin=1, band_stride=2)]
+    got, seg = _frames_on_gpu(renderer, flat, cams, calls)
+    renderer.begin_frames(w, h, len(cams))
+    for f, cam in enumerate(cams):
+        renderer.select_frame(f)
+        renderer.set_camera(cam)
+        for p in calls:
+            renderer.render(p)
+    for f in range(len(cams)):
+        renderer.select_frame(f)
+        assert np.array_equal(_bits(got[f][0]), _bits(renderer.read_accum())), f
+        assert np.array_equal(got[f][1], renderer.read_primary_ids()), f
+        assert np.array_equal(got[f][3], renderer.read_sample_counts()), f
+    assert seg == renderer.ray_count()
+    from raytracing_amd import workloads
+    mesh = workloads.mesh_scene()
+    p = make_params(96, 54, spp=2)
+    got, seg = _frames_on_gpu(renderer, mesh, cams[:3], [p])
+    total = 0
+    for f, cam in enumerate(cams[:3]):
+        acc, ids, s = oracle.render(mesh, cam, tables, p, threads=8)
+        total += s
+        assert np.array_equal(_bits(got[f][0]), _bits(np.ascontiguousarray(acc[..., :3]))), f
+        assert np.array_equal(got[f][1], ids), f
+    assert seg == total
+    from raytracing_amd import _lib
+    with pytest.raises(_lib.RtError):
+        renderer.render_frames(p, cams)            # more cameras than frames
+    with pytest.raises(_lib.RtError):
+        renderer.select_frame(3)
+    renderer.begin_frame(8, 8)                     # back to one frame for the tests that follow
+
+
+@pytest.mark.parametrize("unit_px", [1, 2, 4, 8, 16, 32, 64])
 def test_every_work_unit_size_gives_the_same_picture(renderer, oracle, tables, unit_px):
-    """the launch hands out parts of 8x8 tiles (2 to 64 pixels x the samples of the launch) to
+    """the launch hands out parts of 8x8 tiles (1 to 64 pixels x the samples of the launch) to
     the waves; whatever the size, and with a frame whose right and top tiles are partial
     (61 x 43), the sums are those of the oracle: 3 samples (units of a few items, several in
     flight per wave), 64 and 70 samples (a second launch of 6), two bands out of three, and a
@@ -142,12 +220,16 @@ def test_every_work_unit_size_gives_the_same_picture(renderer, oracle, tables, u
         assert_same(g, o, oracle)
 
 
+@pytest.mark.parametrize("staged", [False, True])
 @pytest.mark.parametrize("n_ctx,w,h", [(1, 61, 43), (2, 120, 67), (3, 61, 43), (5, 64, 64), (8, 33, 9)])
-def test_gather_of_several_contexts(renderer, oracle, tables, n_ctx, w, h):
+def test_gather_of_several_contexts(renderer, oracle, tables, n_ctx, w, h, staged, monkeypatch):
     """rt_gather_packed: n contexts (here all on GPU 0) render the bands b % n == g of one frame; the
     library quantises each share, collects the blocks on the first context's GPU and returns the
     picture in display order.  More contexts than bands (8 on a 9-row frame) leave some with nothing."""
     from raytracing_amd import Renderer, gather_packed
+    if staged:
+        # the blocks of the other contexts go through a staging block and a peer copy, as between GPUs
+        monkeypatch.setenv("RT_HIP_GATHER_STAGED", "1")
     flat = Scene.get_scene().flatten()
     cam = Scene.get_camera(aperture=0.1)
     want = render_oracle(oracle, tables, flat, cam, [make_params(w, h, spp=2)])

@@ -246,3 +246,37 @@ def test_oracle_rejects_malformed_scenes(oracle, tables):
                                      mat_kind=[1], mat_r=[1], mat_g=[1], mat_b=[1], mat_param=[0])
     with pytest.raises(RuntimeError):
         oracle.render(bad_mat, cam, tables, make_params(16, 16))
+
+
+def test_library_build_id_matches_the_kernel_sources():
+    """rt_build_id() is the SHA-256 (first 16 hex digits) of the kernel sources the library in the tree
+    was built from; bench.py uses it to tell whether committed counter passes belong to this build.  A
+    library that is older than the sources next to it fails here."""
+    import hashlib
+    from raytracing_amd import _lib
+    csrc = os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), "csrc")
+    h = hashlib.sha256()
+    for name in ("rt_kernels.hip", "rt_device.h"):
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(f.read())
+    assert _lib.load().rt_build_id().decode() == h.hexdigest()[:16]
+
+
+def test_mesh_workload_comes_through_the_obj_reader(tmp_path):
+    """c3's mesh is data/uv_sphere.obj read by load_obj: 960 triangles whose binary32 coordinates are
+    those of the procedural UV sphere the file was written from, in the same order; writing the file
+    again gives the same bytes"""
+    from raytracing_amd import Lambertian, Scene, Triangle, workloads
+    got = workloads.mesh_scene()
+    scene = Scene.get_scene()
+    mat = Lambertian((0.2, 0.25, 0.6))
+    for a, b, c in workloads.uv_sphere_mesh():
+        scene.add(Triangle(a, b, c, mat))
+    want = scene.flatten()
+    assert got.counts == want.counts and got.counts["n_tris"] == 960
+    for key, arr in want.arrays.items():
+        assert np.array_equal(np.asarray(got.arrays[key]).view(np.uint32), np.asarray(arr).view(np.uint32)), key
+    again = tmp_path / "again.obj"
+    assert workloads.write_mesh_obj(str(again)) == (482, 960)
+    with open(workloads.MESH_OBJ, "rb") as f, open(again, "rb") as g:
+        assert f.read() == g.read()

@@ -177,20 +177,42 @@ def test_driver_with_several_contexts_equals_one(tmp_path, oracle, tables):
     w, spp = 200, 2
     h = image_height(w)
     outs = {}
-    for gpus, extra in ((1, []), (3, ["--same-device"])):
-        outs[gpus] = subprocess.check_output(
+    # (the third run sends the blocks of the two other contexts through their staging blocks and peer
+    # copies, RT_HIP_GATHER_STAGED=1: the path contexts on other GPUs take, here within one device)
+    for name, gpus, extra, env in (("g1", 1, [], {}), ("g3", 3, ["--same-device"], {}),
+                                   ("g3s", 3, ["--same-device"], {"RT_HIP_GATHER_STAGED": "1"})):
+        outs[name] = subprocess.check_output(
             [exe, "--width", str(w), "--spp", str(spp), "--frames", "2", "--aperture", "0.1", "--gpus", str(gpus),
-             "--data", os.path.join(PKG, "data"), "--out", str(tmp_path / ("g%d" % gpus)), "--quiet"] + extra,
-            text=True, timeout=100)
+             "--data", os.path.join(PKG, "data"), "--out", str(tmp_path / name), "--quiet"] + extra,
+            text=True, timeout=100, env=dict(os.environ, **env))
     seg = [o.split('"segments": ')[1].split(",")[0] for o in outs.values()]
-    assert seg[0] == seg[1] and '"gpus": 3' in outs[3]
+    assert seg[0] == seg[1] == seg[2] and '"gpus": 3' in outs["g3"]
     flat = Scene.get_scene().flatten()
     for frame in range(2):
         one = _read_ppm(str(tmp_path / ("g1_%04d.ppm" % frame)))
         three = _read_ppm(str(tmp_path / ("g3_%04d.ppm" % frame)))
-        assert np.array_equal(one, three), frame
+        staged = _read_ppm(str(tmp_path / ("g3s_%04d.ppm" % frame)))
+        assert np.array_equal(one, three) and np.array_equal(one, staged), frame
         acc, _, _ = oracle.render(flat, oracle.scene_camera(frame, 0.1), tables, make_params(w, h, spp=spp))
         assert np.array_equal(three, oracle.pack(acc)), frame
+
+
+@pytest.mark.gpu
+def test_driver_batch_of_frames_equals_frame_by_frame(tmp_path):
+    """rt_main --batch: the ten frames of the reference's run (600 x 337, 1 sample, the camera one dolly
+    step further each frame) in one rt_render_frames call give the pictures and the segment count of
+    the frame-by-frame run"""
+    exe = os.path.join(PKG, "rt_main")
+    outs = {}
+    for name, extra in (("seq", []), ("batch", ["--batch"])):
+        outs[name] = subprocess.check_output(
+            [exe, "--frames", "10", "--data", os.path.join(PKG, "data"), "--out", str(tmp_path / name), "--quiet"] + extra,
+            text=True, timeout=100)
+    seg = [o.split('"segments": ')[1].split(",")[0] for o in outs.values()]
+    assert seg[0] == seg[1] and int(seg[0]) > 0
+    for frame in range(10):
+        assert np.array_equal(_read_ppm(str(tmp_path / ("seq_%04d.ppm" % frame))),
+                              _read_ppm(str(tmp_path / ("batch_%04d.ppm" % frame)))), frame
 
 
 @pytest.mark.gpu

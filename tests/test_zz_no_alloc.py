@@ -83,12 +83,64 @@ def test_static_scratch_entry_point_equals_rt_render(renderer):
     _same(_static(renderer, flat1, cam1, p1), want1)
     _same(_static(renderer, flat2, cam2, p2), want2)      # smaller input right after a larger one
     _same(_static(renderer, flat1, cam1, p1), want1)
-    # 150 samples = three launches (64 + 64 + 22) sharing the ring, in two calls; one band share
+    # 150 samples in two calls (units of a few pixels), 600 samples = two launches (512 + 88) sharing
+    # the ring; one band share
     p3 = [make_params(40, 24, spp=150, sample_begin=0, sample_count=70),
           make_params(40, 24, spp=150, sample_begin=70, sample_count=80)]
     _same(_static(renderer, flat2, cam2, p3), _reference(renderer, flat2, cam2, p3))
+    p5 = [make_params(21, 13, spp=600)]
+    _same(_static(renderer, flat2, cam2, p5), _reference(renderer, flat2, cam2, p5))
     p4 = [make_params(120, 67, spp=2, band_begin=1, band_stride=3)]
     _same(_static(renderer, flat2, cam2, p4), _reference(renderer, flat2, cam2, p4))
+
+
+def _free_device_memory():
+    hip = DeviceBuffer.hip
+    free, total = C.c_size_t(), C.c_size_t()
+    assert hip.hipDeviceSynchronize() == 0
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
+def test_static_entry_point_allocates_nothing(tables):
+    """what the entry point is for: on a context that never had a frame (no staging ring, no per-pixel
+    buffers of the library's own) calls of different frame sizes, sample ranges, scenes and kernels leave
+    the device's free memory where it was after a warm-up call of each kernel.  The context's stream is
+    handed out without a frame, with null buffers."""
+    from raytracing_amd import Renderer
+    big = workloads.workload("c4")
+    small, cam_small = Scene.get_scene().flatten(), Scene.get_camera(aperture=0.1)
+    outputs = [DeviceBuffer(640 * 360 * 16, 0), DeviceBuffer(640 * 360 * 4, 0xff), DeviceBuffer(8, 0)]
+    DeviceBuffer.hip.hipMemGetInfo.restype = C.c_int
+    with Renderer(0, tables) as r:
+        accum, packed, ids, stream = r.device_buffers()
+        assert accum is None and packed is None and ids is None and stream
+        calls = [(big["flat"], big["camera"], make_params(640, 360, spp=2)),
+                 (small, cam_small, make_params(61, 43, spp=3)),
+                 (small, cam_small, make_params(21, 13, spp=600)),                     # two launches
+                 (big["flat"], big["camera"], make_params(320, 180, spp=4, max_bounces=16)),   # the deep kernel
+                 (small, cam_small, make_params(120, 67, spp=2, band_begin=1, band_stride=3))]
+
+        def run(flat, cam, p):
+            r.set_camera(cam)
+            r.render_static(p, outputs[0].ptr.value, outputs[1].ptr.value, outputs[2].ptr.value)
+            r.sync()
+
+        # scenes are uploaded (that allocates) and every kernel has run once before the measurement
+        r.set_scene(big["flat"])
+        run(*calls[0]); run(*calls[3])
+        before_big = _free_device_memory()
+        for flat, cam, p in (calls[0], calls[3], calls[0]):
+            run(flat, cam, p)
+        assert _free_device_memory() == before_big
+        r.set_scene(small)
+        run(*calls[1])
+        before_small = _free_device_memory()
+        for flat, cam, p in (calls[1], calls[2], calls[4], calls[1]):
+            run(flat, cam, p)
+        assert _free_device_memory() == before_small
+    for b in outputs:
+        b.free()
 
 
 def test_static_entry_point_rejects_bad_arguments(renderer):

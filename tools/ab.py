@@ -12,7 +12,7 @@ import zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def child(lib, workloads, launches, checksum):
+def child(lib, workloads, launches, checksum, sps_max=64):
     os.environ["RT_HIP_LIBRARY"] = os.path.abspath(lib)
     sys.path.insert(0, ROOT)
     from raytracing_amd import Renderer, load_tables, make_params, workloads as wls
@@ -20,7 +20,7 @@ def child(lib, workloads, launches, checksum):
     for name in workloads:
         wl = wls.workload(name)
         w, h, spp = wl["width"], wl["height"], wl["spp"]
-        sps = min(64, spp)
+        sps = min(sps_max, spp)
         with Renderer(0, tables) as r:
             r.set_scene(wl["flat"]); r.set_camera(wl["camera"]); r.begin_frame(w, h)
             r.render(make_params(w, h, spp=spp, sample_begin=0, sample_count=sps)); r.sync()
@@ -44,15 +44,16 @@ def main():
     ap.add_argument("--launches", type=int, default=5)
     ap.add_argument("--checksum", action="store_true")
     ap.add_argument("--child", action="store_true")
+    ap.add_argument("--sps", type=int, default=64, help="samples per rt_render call")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
     wl = [x for x in a.workloads.split(",") if x]
     if a.child:
-        child(a.libs[0], wl, a.launches, a.checksum)
+        child(a.libs[0], wl, a.launches, a.checksum, a.sps)
         return
     for lib in a.libs:
         cmd = [sys.executable, os.path.abspath(__file__), "--child", "--workloads", a.workloads,
-               "--launches", str(a.launches), lib] + (["--checksum"] if a.checksum else [])
+               "--launches", str(a.launches), "--sps", str(a.sps), lib] + (["--checksum"] if a.checksum else [])
         rc = subprocess.run(cmd, timeout=400).returncode
         if rc != 0:
             sys.exit(rc)

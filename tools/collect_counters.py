@@ -54,8 +54,11 @@ def main():
     sps = bench["config"]["spp_per_step"]
     a, n_a, kernel = per_launch(os.path.join(d, "pmc_sq_a.csv"))
     lanes = a["SQ_THREAD_CYCLES_VALU"] / a["SQ_ACTIVE_INST_VALU"]
+    sps = -(-sps // bench["config"].get("launches_per_step", 1))
+    seg = seg / bench["config"].get("launches_per_step", 1)
+    build = bench["roofline"].get("library_build")
     rec = {
-        "kernel": kernel, "launches_averaged": n_a, "spp_per_launch": sps, "segments_per_launch": seg,
+        "kernel": kernel, "library_build": build, "launches_averaged": n_a, "spp_per_launch": sps, "segments_per_launch": seg,
         "per_launch": dict(a),
         "active_lanes_per_valu_inst": round(lanes, 2),
         "valu_lane_ops_per_segment": round(a["SQ_INSTS_VALU"] * lanes / seg, 1),
@@ -79,6 +82,7 @@ def main():
         f_, n_f, _ = per_launch(pf)
         w_, _, _ = per_launch(pw)
         hbm = {
+            "library_build": build,
             "bytes_per_launch": int(2 * f_["FETCH_SIZE"] * 1024 + w_["WRITE_SIZE"] * 1024),
             "fetch_size_kib_raw": f_["FETCH_SIZE"], "write_size_kib_raw": w_["WRITE_SIZE"],
             "launches_averaged": n_f, "spp_per_launch": sps,

@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
-"""Generates tools/ub_issue2.hip: issue-cost microbenchmarks for mixes of gfx950 VALU
-instructions.  Each variant is a list of 8 instruction templates; {d} = k-th destination
-VGPR, {dp} = k-th destination VGPR pair, {a},{b} VGPRs, {ap},{bp} VGPR pairs, {s} SGPR, {sp} SGPR pair."""
+"""Generates build/ub_issue2.hip (not kept in the repository) and, with --build, compiles it to
+tools/ub_issue2: issue-cost microbenchmarks for mixes of gfx950 VALU instructions.  Each variant is a
+list of 8 instruction templates; {d} = k-th destination VGPR, {dp} = k-th destination VGPR pair,
+{a},{b} VGPRs, {ap},{bp} VGPR pairs, {s} SGPR, {sp} SGPR pair.
+usage: gen_ub_issue2.py [--build] [--only SUBSTRING[,SUBSTRING...]]"""
+import os
+import subprocess
+import sys
 V = {
  "mul vgpr": ["v_mul_f32_e32 {d}, {a}, {b}"] * 8,
  "add vgpr": ["v_add_f32_e32 {d}, {a}, {b}"] * 8,
@@ -72,6 +77,39 @@ V = {
  "lshl_add_u32": ["v_lshl_add_u32 {d}, {a}, 3, {b}"] * 8,
  "mul dependent chain (1 reg)": ["v_mul_f32_e32 {d0}, {d0}, {b}"] * 8,
  "fma dependent chain (1 reg)": ["v_fma_f32 {d0}, {d0}, {b}, {b}"] * 8,
+ # integer and bit forms a slab test could use instead of the f32 ones
+ "int: max_i32": ["v_max_i32_e32 {d}, {a}, {b}"] * 8,
+ "int: min_i32": ["v_min_i32_e32 {d}, {a}, {b}"] * 8,
+ "int: max_u32": ["v_max_u32_e32 {d}, {a}, {b}"] * 8,
+ "int: max3_i32": ["v_max3_i32 {d}, {a}, {b}, {b}"] * 8,
+ "int: min3_i32": ["v_min3_i32 {d}, {a}, {b}, {b}"] * 8,
+ "int: min3_u32": ["v_min3_u32 {d}, {a}, {b}, {b}"] * 8,
+ "int: med3_i32": ["v_med3_i32 {d}, {a}, {b}, {b}"] * 8,
+ "int: cmp_lt_i32 -> vcc": ["v_cmp_lt_i32_e32 vcc, {a}, {d}"] * 8,
+ "int: cmp_lt_u32 -> vcc": ["v_cmp_lt_u32_e32 vcc, {a}, {d}"] * 8,
+ "int: addc_co_u32 vcc": ["v_addc_co_u32_e32 {d}, vcc, {a}, {b}, vcc"] * 8,
+ "int: add_u32": ["v_add_u32_e32 {d}, {a}, {b}"] * 8,
+ "int: sub_u32": ["v_sub_u32_e32 {d}, {a}, {b}"] * 8,
+ "int: sub_co_u32": ["v_sub_co_u32_e32 {d}, vcc, {a}, {b}"] * 8,
+ "int: alignbit": ["v_alignbit_b32 {d}, {a}, {b}, 31"] * 8,
+ "int: lshl_or": ["v_lshl_or_b32 {d}, {a}, 1, {b}"] * 8,
+ "int: or3": ["v_or3_b32 {d}, {a}, {b}, {b}"] * 8,
+ "int: xor": ["v_xor_b32_e32 {d}, {a}, {b}"] * 8,
+ "int: or": ["v_or_b32_e32 {d}, {a}, {b}"] * 8,
+ "int: lshlrev": ["v_lshlrev_b32_e32 {d}, 3, {a}"] * 8,
+ "int: perm": ["v_perm_b32 {d}, {a}, {b}, {b}"] * 8,
+ "int: cvt_i32_f32": ["v_cvt_i32_f32_e32 {d}, {a}"] * 8,
+ "int: bfe_u32": ["v_bfe_u32 {d}, {a}, 3, 5"] * 8,
+ "int: add3_u32": ["v_add3_u32 {d}, {a}, {b}, {b}"] * 8,
+ "int: mov_b64": ["v_mov_b64 {dp}, {ap}"] * 8,
+ "int: pk_mov_b32": ["v_pk_mov_b32 {dp}, {ap}, {bp}"] * 8,
+ "int: cmp_gt_f32 e64 -> sgpr": ["v_cmp_gt_f32_e64 s[22:23], {a}, {d}"] * 8,
+ "int: alt max_i32/min_i32": ["v_max_i32_e32 {d}, {a}, {b}", "v_min_i32_e32 {d}, {a}, {b}"] * 4,
+ "int: alt pk_fma/max_i32/max_i32/min_i32": ["v_pk_fma_f32 {dp}, {ap}, {bp}, {bp}", "v_max_i32_e32 {d}, {a}, {b}", "v_max_i32_e32 {d}, {a}, {b}", "v_min_i32_e32 {d}, {a}, {b}"] * 2,
+ "int: alt pk_fma/max3_f32/min3_f32/sub": ["v_pk_fma_f32 {dp}, {ap}, {bp}, {bp}", "v_max3_f32 {d}, {a}, {b}, {b}", "v_min3_f32 {d}, {a}, {b}, {b}", "v_sub_f32_e32 {d}, {a}, {b}"] * 2,
+ "int: cmp f32 then addc": ["v_cmp_lt_f32_e32 vcc, {a}, {b}", "v_addc_co_u32_e32 {d}, vcc, {a}, {a}, vcc"] * 4,
+ "int: mul_f32 dpp quad_perm": ["v_mul_f32_dpp {d}, {a}, {b} quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"] * 8,
+ "int: mov_b32 dpp row_shr:1": ["v_mov_b32_dpp {d}, {a} row_shr:1 row_mask:0xf bank_mask:0xf"] * 8,
 }
 out = ['#include <hip/hip_runtime.h>', '#include <cstdio>', 'typedef float f2 __attribute__((ext_vector_type(2)));',
        'template <int V> __global__ __launch_bounds__(256) void k(float *out, int iters, float sa, float sb) {',
@@ -79,7 +117,10 @@ out = ['#include <hip/hip_runtime.h>', '#include <cstdio>', 'typedef float f2 __
        '  f2 r0 = {0,0}, r1 = {0,0}, r2 = {0,0}, r3 = {0,0}, r4 = {0,0}, r5 = {0,0}, r6 = {0,0}, r7 = {0,0};',
        '  float q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, q6 = 0, q7 = 0;',
        '  for (int it = 0; it < iters; ++it) {']
-names = list(V)
+only = None
+if "--only" in sys.argv:
+    only = sys.argv[sys.argv.index("--only") + 1].split(",")
+names = [n for n in V if only is None or any(o in n for o in only)]
 for vi, name in enumerate(names):
     lines = []
     for rep in range(8):
@@ -103,4 +144,9 @@ out += ['  }', '  out[blockIdx.x * 256 + threadIdx.x] = r0.x + r1.x + r2.x + r3.
 for vi, name in enumerate(names):
     out.append('  run<%d>("%s", out);' % (vi, name))
 out += ['  return 0; }']
-open("tools/ub_issue2.hip", "w").write("\n".join(out) + "\n")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+SRC = os.path.join(ROOT, "build", "ub_issue2.hip")
+open(SRC, "w").write("\n".join(out) + "\n")
+if "--build" in sys.argv:
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-o", os.path.join(ROOT, "tools", "ub_issue2"), SRC])

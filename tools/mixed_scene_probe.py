@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Development aid: kernel time of a scene with a middling sphere run (48) next to a long triangle
 run (3000) at 1080p, 64 spp, and a CRC of the picture, for the library named by RT_HIP_LIBRARY.
-usage: [RT_HIP_LIBRARY=lib.so] mixed_scene_probe.py"""
+With --spheres-only the triangles are left out: a scene whose only long run is 48 spheres, which the
+library walks through a small box tree (render_tiles<2, 10>) and, with RT_HIP_FLAT_SCAN=1 in the
+environment, scans in list order through the rejection test (render_tiles<1, 16>).
+usage: [RT_HIP_LIBRARY=lib.so] [RT_HIP_FLAT_SCAN=1] mixed_scene_probe.py [--spheres-only]"""
 import os
 import sys
 import zlib
@@ -14,7 +17,7 @@ s.add(Plane((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), Lambertian((0.5, 0.5, 0.5))))
 for _ in range(48):
     c = rng.uniform(-4, 4, 3); c[1] = abs(c[1]) * 0.3
     s.add(Sphere(tuple(c), float(rng.uniform(0.1, 0.5)), Metal(tuple(rng.uniform(0.3, 0.9, 3)), 0.1)))
-for _ in range(3000):
+for _ in range(0 if "--spheres-only" in sys.argv else 3000):
     a = rng.uniform(-5, 5, 3); a[1] = abs(a[1]) * 0.5
     s.add(Triangle(tuple(a), tuple(a + rng.uniform(-0.3, 0.3, 3)), tuple(a + rng.uniform(-0.3, 0.3, 3)), Lambertian(tuple(rng.uniform(0.2, 0.9, 3)))))
 flat = s.flatten()
@@ -27,4 +30,5 @@ with Renderer(0, load_tables()) as r:
     ms = []
     for k in range(4):
         r.timer_start(); r.render(make_params(w, h, spp=64, sample_begin=0, sample_count=64)); ms.append(r.timer_stop())
-    print(os.environ.get("RT_HIP_LIBRARY", "default"), "48 spheres + 3000 triangles 1080p 64 spp: best %.3f ms" % min(ms), "crc %08x" % zlib.crc32(r.read_packed().tobytes()))
+    print(os.environ.get("RT_HIP_LIBRARY", "default"), r.kernel_variant(), "48 spheres + %d triangles 1080p 64 spp: best %.3f ms" % (flat.counts["n_tris"], min(ms)),
+          "crc %08x" % zlib.crc32(r.read_packed().tobytes()))

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Collects what is committed under profiles/ in one GPU session:
 #   - kernel trace + stats of the default bench.py run (the line the driver records),
-#   - per workload (default: c4 c2 c5) four counter passes of a short bench.py run: two SQ passes
+#   - per workload (default: all five) four counter passes of a short bench.py run: two SQ passes
 #     (issue and lane counters; instruction types), HBM reads, HBM writes.
 # Outputs land in gpurun_out/prof/<workload>/; copy into profiles/ with tools/collect_counters.py.
 # usage: tools/profile_round.sh <tag> [workloads...]      (e.g. r02 c4 c2)
 set -u
 TAG=${1:-r02}; shift
-WLS=${*:-c4 c2 c5}
+WLS=${*:-c1 c2 c3 c4 c5}
 OUT=gpurun_out/prof
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -15,7 +15,9 @@ timeout -s KILL 400 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --ou
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_default_kernel_stats.csv
 for W in $WLS; do
   D=$OUT/$W; mkdir -p $D
-  SHORT="--workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-flat-probe --others="
+  # (a step is the whole frame, up to 512 samples per launch: c5 takes two launches per step, one step is enough)
+  STEPS=2; [ $W = c5 ] && STEPS=1
+  SHORT="--workload $W --steps $STEPS --warmup 1 --no-cpu-baseline --no-flat-probe --others="
   timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SALU SQ_WAIT_INST_ANY -d $D/sq_a -o sq_a --output-format csv -- python3 bench.py $SHORT > $D/bench_sq_a.json 2> $D/sq_a.err || exit 1
   timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_LDS SQ_INSTS_VMEM_RD -d $D/sq_b -o sq_b --output-format csv -- python3 bench.py $SHORT > $D/bench_sq_b.json 2> $D/sq_b.err || exit 1
   timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $D/fetch -o fetch --output-format csv -- python3 bench.py $SHORT > $D/bench_fetch.json 2> $D/fetch.err || exit 1

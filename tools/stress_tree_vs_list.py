@@ -2,7 +2,8 @@
 (RT_HIP_FLAT_SCAN=1 disables the tree; triangles then run their exact test one by one
 and spheres the rejection scan), over random scenes at frame sizes far beyond the CPU
 oracle.  Every output must be bit-identical.
-usage: stress_tree_vs_list.py [seconds] [seed0] [share of scenes with NaN/inf/huge/tiny numbers, default 0]"""
+usage: stress_tree_vs_list.py [seconds | <count>n] [seed0] [share of scenes with NaN/inf/huge/tiny numbers, default 0]
+(a budget written as `80n` is a number of scenes instead of a time)"""
 import os
 import sys
 import time
@@ -131,7 +132,9 @@ def perturb(rng, flat, cam, share):
 
 
 def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    arg = sys.argv[1] if len(sys.argv) > 1 else "60"
+    n_scenes = int(arg[:-1]) if arg.endswith("n") else None      # a budget of scenes instead of seconds
+    budget = float("inf") if n_scenes is not None else float(arg)
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     share = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
     r = Renderer(0, load_tables())
@@ -139,7 +142,7 @@ def main():
     k = 0
     rays = 0
     bad = 0
-    while time.time() - t0 < budget:
+    while time.time() - t0 < budget and (n_scenes is None or k < n_scenes):
         rng = np.random.default_rng(seed0 + k)
         flat, cam = scene(rng)
         notes = perturb(rng, flat, cam, share) if share > 0.0 else []
