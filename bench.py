@@ -253,14 +253,14 @@ def flat_scan_probe(r, wl, flops_seg):
 
 
 def other_workload(name, tables, launches=3):
-    """A short single-GPU measurement of another configuration: `launches` launches of up to 256 spp of
+    """A short single-GPU measurement of another configuration: `launches` launches of up to 512 spp of
     the full frame after one warm-up, kernel time from HIP events.  A workload that is a run of several
     frames (c1: the reference's ten) is rendered the way the library offers for that, all frames in one
     rt_render_frames launch; the time of its first frame alone in a launch of its own is given beside it."""
     from raytracing_amd import Renderer, make_params, workloads
     wl = workloads.workload(name)
     w, h, spp = wl["width"], wl["height"], wl["spp"]
-    sps = min(256, spp)
+    sps = min(512, spp)
     cams = wl.get("cameras")
     n_frames = len(cams) if cams else 1
     flops_seg = workloads.flops_per_segment(wl["flat"])

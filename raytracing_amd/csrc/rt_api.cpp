@@ -42,6 +42,7 @@ struct Ctx {
     uint32_t *d_packed = nullptr;
     int32_t *d_ids = nullptr;
     rt_camera *d_cams = nullptr;      // the cameras of the last rt_render_frames, n_frames of them
+    std::vector<rt_camera> cams_host; // what d_cams holds
     // the selected frame's part of the three buffers
     size_t frame_px() const { return (size_t)W * H; }
     float4 *accum() const { return d_accum + frame_px() * sel; }
@@ -91,7 +92,7 @@ void free_frame(Ctx *c) {
     if (c->d_packed) (void)hipFree(c->d_packed);
     if (c->d_ids) (void)hipFree(c->d_ids);
     if (c->d_cams) (void)hipFree(c->d_cams);
-    c->d_cams = nullptr; c->n_frames = 0; c->sel = 0;
+    c->d_cams = nullptr; c->n_frames = 0; c->sel = 0; c->cams_host.clear();
     if (c->d_block) (void)hipFree(c->d_block);
     if (c->d_gather) (void)hipFree(c->d_gather);
     c->d_block = nullptr; c->d_gather = nullptr; c->block_px = c->gather_px = 0;
@@ -392,7 +393,11 @@ int rt_render_frames(rt_ctx *ctx, const rt_params *p, const rt_camera *cameras, 
     if (rtk_has_frames_kernel(c->dsc.modes)) {
         // one launch (per 512 samples) over the tiles of all frames; the cameras go to device memory first
         // (the copy from the caller's pageable memory has left it when the call returns)
-        HIP_TRY(c, hipMemcpyAsync(c->d_cams, cameras, n_frames * sizeof(rt_camera), hipMemcpyHostToDevice, c->stream));
+        // (not when they are the cameras that are there already: progressive calls on the same frames)
+        if (c->cams_host.size() != n_frames || std::memcmp(c->cams_host.data(), cameras, n_frames * sizeof(rt_camera)) != 0) {
+            c->cams_host.assign(cameras, cameras + n_frames);
+            HIP_TRY(c, hipMemcpyAsync(c->d_cams, c->cams_host.data(), n_frames * sizeof(rt_camera), hipMemcpyHostToDevice, c->stream));
+        }
         DevFrame fr{c->d_disc, c->d_sphere, c->d_screen, c->d_accum, c->d_ids, c->d_stage, c->d_segments,
                     nullptr, nullptr, 0u};
         return enqueue_render(c, p, fr, c->stage_waves, c->d_queue, nullptr, 0, c->d_cams, n_frames);

@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 
 #include "rt_device.h"
@@ -1170,6 +1171,7 @@ constexpr uint32_t ITEM_BITS = DEV_STAGE_ITEM_BITS;   // item index inside a uni
 struct KernArgs {
     DevScene dsc; rt_camera cam; rt_params p; DevFrame fr; uint32_t n_bands, unit_px_log2, stretch_unit, fetch_min;
     const rt_camera *cams; uint32_t n_frames;
+    uint32_t unit_batch;   // consecutive units a wave takes by position at first, and per request to the counter
 };
 
 // FRAMES: the launch covers n_frames frames of one size with a camera each (the reference renders ten
@@ -1250,10 +1252,17 @@ void render_tiles(KernArgs by_value) {
     // (a wave's first unit is the one with its own number: thousands of waves asking the counter
     // in the launch's first microsecond would queue up behind one another - the counter hands out
     // the units after those)
+    // Units come in batches of unit_batch consecutive ones (1 unless the launch's units are short: at one
+    // sample per pixel a unit, a whole tile, is 64 items instead of 512, and single units of that size
+    // would be asked for faster than the counter answers, about 90 requests per microsecond: ten frames
+    // of 600 x 337 at one sample took 0.50 ms that way and 0.27 ms of it was the counter).  Only the
+    // kernels that hand out stretches at all (those with a tree, and FRAMES) do this.
+    constexpr bool STRETCHES = (MODES & 2) != 0 || FRAMES;
+    const uint32_t unit_batch = STRETCHES ? args0->unit_batch : 1u;
     const uint32_t grid_waves = gridDim.x * (uint32_t)waves_of(MODES);
-    uint32_t unit_ahead = blockIdx.x * (uint32_t)waves_of(MODES) + wave;
+    uint32_t unit_ahead = (blockIdx.x * (uint32_t)waves_of(MODES) + wave) * unit_batch;
     // units the wave may still take from the stretch it was given last (wave-uniform)
-    uint32_t stretch_next = 0u, stretch_end = 0u, asked = 1u;   // asked: units of the request on the way
+    uint32_t stretch_next = 0u, stretch_end = 0u, asked = unit_batch;   // asked: units of the request on the way
 
     struct Where { uint32_t i, j, s, f; };      // column, row from the bottom, sample, frame of the launch
     auto where = [&](uint32_t it) {
@@ -1286,7 +1295,7 @@ void render_tiles(KernArgs by_value) {
         float u, v;
         if (cheap_uv) { u = div_refined((float)w.i + ox, w1, inv_w1); v = div_refined((float)w.j + oy, h1, inv_h1); }
         else { u = ((float)w.i + ox) / w1; v = ((float)w.j + oy) / h1; }
-        if (FRAMES) ray = get_ray(k->cams[w.f], u, v, la, lb);
+        if (FRAMES && k->n_frames > 1u) ray = get_ray(k->cams[w.f], u, v, la, lb);
         else ray = get_ray(k->cam, u, v, la, lb);
         path_counter = path_key_at(w, k->p.seed);
         // BlueNoise::get_screenspace, src/denoising/mod.rs:19-23: fixed per pixel, kept for the path
@@ -1376,7 +1385,7 @@ void render_tiles(KernArgs by_value) {
                 uint32_t u;
                 // (only the kernels with a tree: a scene without one has short launches, and the
                 // three wave-uniform values cost its kernel more than the requests they save)
-                if ((MODES & 2) && stretch_next < stretch_end) {
+                if (STRETCHES && stretch_next < stretch_end) {
                     u = stretch_next++;
                 } else {
                     u = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit_ahead);
@@ -1386,15 +1395,15 @@ void render_tiles(KernArgs by_value) {
                     // triangles at 4K ask 21 times per microsecond): a few units while much is left,
                     // single units afterwards (see rtk_launch_render).  A wave's first unit, by
                     // position, is a stretch of one.
+                    if (STRETCHES) { stretch_next = u + 1u; stretch_end = min(u + asked, n_units); }
                     if (MODES & 2) {
-                        if (u >= grid_waves) { stretch_next = u + 1u; stretch_end = min(u + asked, n_units); }
-                        const uint32_t left = n_units - u, per = k->stretch_unit;   // per: 32 units for every wave
-                        asked = left >= 8u * per ? 8u : left >= 4u * per ? 4u : left >= 2u * per ? 2u : 1u;
+                        const uint32_t left = n_units - u, per = k->stretch_unit;   // per: 32 batches for every wave
+                        asked = (left >= 8u * per ? 8u : left >= 4u * per ? 4u : left >= 2u * per ? 2u : 1u) * unit_batch;
                     }
-                    // (a launch with no more units than waves never asks the counter: thousands of
+                    // (a launch with no more batches than waves never asks the counter: thousands of
                     // requests for nothing take 30 us to answer)
-                    if (grid_waves >= n_units) unit_ahead = n_units;
-                    else if (lane == 0u) unit_ahead = grid_waves + atomicAdd(k->fr.queue, asked);
+                    if (grid_waves * unit_batch >= n_units) unit_ahead = n_units;
+                    else if (lane == 0u) unit_ahead = grid_waves * unit_batch + atomicAdd(k->fr.queue, asked);
                 }
                 const uint32_t t = u >> sub_log2, sub = u & ((1u << sub_log2) - 1u);
                 uint32_t by = t / tiles_x;
@@ -1750,9 +1759,12 @@ hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_
                              int unit_px_log2, hipStream_t stream, const rt_camera *cams, uint32_t n_frames) {
     const uint32_t waves = (uint32_t)rtk::waves_of((int)(sc.modes & 3u));
     const uint32_t tiles_x = (p.width + rtk::TILE - 1u) / rtk::TILE;
-    const bool frames = cams != nullptr;
+    bool frames = cams != nullptr;
     if (frames && (n_frames == 0u || !rtk_has_frames_kernel(sc.modes))) return hipErrorInvalidValue;
-    const uint64_t n_tiles = (uint64_t)tiles_x * n_bands * (frames ? n_frames : 1u);
+    if (!frames) n_frames = 1u;
+    // (a launch of a scene without long runs whose units are short goes to the same kernel, as one frame)
+    if (!frames && rtk_has_frames_kernel(sc.modes) && p.sample_count * 64u <= (1u << DEV_STAGE_ITEM_BITS) / 2u) frames = true;
+    const uint64_t n_tiles = (uint64_t)tiles_x * n_bands * n_frames;
     // workgroups the chip holds at once (what the kernel is written for, and no more than the runtime
     // says fit a CU: a workgroup that is not resident would start its first unit when another one ends),
     // and the staging ring has room for
@@ -1781,7 +1793,10 @@ hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_
     const uint64_t n_units = n_tiles << (6 - unit_px_log2);
     if (n_units >= 0xffffffffull - 64u * resident * waves) return hipErrorInvalidValue;   // unit numbers handed out: below n_units + waves x (1 + stretch)
     // as many workgroups as the chip holds, fewer when there are not that many work units
-    const uint64_t groups = std::max<uint64_t>(1u, std::min<uint64_t>(resident, (n_units + waves - 1u) / waves));
+    uint64_t groups = std::max<uint64_t>(1u, std::min<uint64_t>(resident, (n_units + waves - 1u) / waves));
+    // development aid: RT_HIP_GROUPS=n fixes the number of workgroups (at most what is resident)
+    if (const char *env = std::getenv("RT_HIP_GROUPS"))
+        if (std::atoi(env) > 0) groups = std::min<uint64_t>(resident, (uint64_t)std::atoi(env));
     dim3 grid((uint32_t)groups, 1, 1), block(waves * 64, 1, 1);
     const uint32_t r = (uint32_t)unit_px_log2;
     // Units per request to the queue counter: 8, 4 or 2 while every wave still has 8, 4 or 2 times 32
@@ -1790,11 +1805,17 @@ hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_
     // start, 4.5 without; a wave's stretch on the way was asked for a stretch earlier), so they are
     // used only while much is left, and only by the kernels with a tree: 10,000 spheres 4K -0.4 %, a
     // million triangles -1 %.
-    const uint64_t stretch_unit = std::min<uint64_t>(32u * groups * waves, 0x1fffffffu);
+    // Short units (a launch of less than eight samples: whole tiles with fewer than 512 items) come in
+    // batches that make up for it, as far as every wave still gets a batch
+    const uint64_t unit_items = (uint64_t)p.sample_count << unit_px_log2;
+    uint64_t unit_batch = 1u;
+    if ((frames || (sc.modes & 2u)) && unit_items != 0u)
+        unit_batch = std::max<uint64_t>(1u, std::min<uint64_t>(max_items / unit_items, (n_units + groups * waves - 1u) / (groups * waves)));
+    const uint64_t stretch_unit = std::min<uint64_t>(32u * groups * waves * unit_batch, 0x1fffffffu);
     // idle lanes a wave waits for before it hands out new work items
     const uint32_t fetch_min = (sc.modes & 3u) == 0u ? RTK_FETCH_MIN0
                                : ((sc.modes & 2u) && sc.lds_kind == DEV_TRI) ? RTK_FETCH_MIN_TRI : RTK_FETCH_MIN;
-    rtk::KernArgs ka{sc, cam, p, fr, n_bands, r, (uint32_t)stretch_unit, fetch_min, cams, frames ? n_frames : 1u};
+    rtk::KernArgs ka{sc, cam, p, fr, n_bands, r, (uint32_t)stretch_unit, fetch_min, cams, n_frames, (uint32_t)unit_batch};
     if (p.max_bounces > RT_MAX_BOUNCES) return hipErrorInvalidValue;
     const uint32_t which = frames ? 8u : kernel_index(sc.modes, p.max_bounces);
     if (which >= 4u) {
