@@ -144,6 +144,30 @@ impl GpuRenderer {
         check(self.ctx, unsafe { rt_ray_count(self.ctx, &mut segments) })?;
         Ok(segments)
     }
+    /// The frames of one run (NUM_FRAMES_TO_RENDER cameras, one per frame) in a single call:
+    /// frame f is rendered through `cameras[f]` and handed to `show(f, pixels)` in order.  For the
+    /// reference's own scene the frames share one kernel launch.
+    pub fn render_frames<F: FnMut(usize, &[u32])>(&mut self, width: usize, height: usize, spp: u32,
+                                                  max_bounces: u32, gamma: bool, cameras: &[rt_camera],
+                                                  mut show: F) -> Result<u64, String> {
+        let p = rt_params {
+            width: width as u32, height: height as u32, spp, sample_begin: 0, sample_count: spp,
+            max_bounces, gamma: gamma as u32, t_min: 0.001, band_begin: 0, band_stride: 1,
+            sampling_mode: RT_SAMPLING_DET, seed: 0,
+        };
+        let n = cameras.len() as u32;
+        check(self.ctx, unsafe { rt_begin_frames(self.ctx, p.width, p.height, n) })?;
+        check(self.ctx, unsafe { rt_render_frames(self.ctx, &p, cameras.as_ptr(), n) })?;
+        let mut pixels = vec![0u32; width * height];
+        for f in 0..cameras.len() {
+            check(self.ctx, unsafe { rt_select_frame(self.ctx, f as u32) })?;
+            check(self.ctx, unsafe { rt_read_packed(self.ctx, pixels.as_mut_ptr(), pixels.len()) })?;
+            show(f, &pixels);
+        }
+        let mut segments = 0u64;
+        check(self.ctx, unsafe { rt_ray_count(self.ctx, &mut segments) })?;
+        Ok(segments)
+    }
 }
 
 impl Drop for GpuRenderer {

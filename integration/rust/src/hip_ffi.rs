@@ -107,7 +107,11 @@ extern "C" {
     pub fn rt_upload_scene(ctx: *mut rt_ctx, scene: *const rt_scene) -> c_int;
     pub fn rt_set_camera(ctx: *mut rt_ctx, cam: *const rt_camera) -> c_int;
     pub fn rt_begin_frame(ctx: *mut rt_ctx, width: u32, height: u32) -> c_int;
+    pub fn rt_begin_frames(ctx: *mut rt_ctx, width: u32, height: u32, n_frames: u32) -> c_int;
+    pub fn rt_select_frame(ctx: *mut rt_ctx, frame: u32) -> c_int;
     pub fn rt_render(ctx: *mut rt_ctx, params: *const rt_params) -> c_int;
+    pub fn rt_render_frames(ctx: *mut rt_ctx, params: *const rt_params, cameras: *const rt_camera,
+                            n_frames: u32) -> c_int;
     /// rt_render on caller-owned device buffers, working memory from the library's fixed
     /// per-GPU scratch: makes no allocation (for callers under graph capture)
     pub fn rt_render_static(ctx: *mut rt_ctx, params: *const rt_params, accum_device: *mut c_void,
@@ -127,6 +131,8 @@ extern "C" {
                                   band_begin: u32, band_stride: u32) -> c_int;
     /// self-check: short division / square-root sequences against `/` and sqrt on the GPU
     pub fn rt_check_arith(ctx: *mut rt_ctx, operands: u64, seed: u32, mismatches: *mut u64) -> c_int;
+    pub fn rt_kernel_info(ctx: *mut rt_ctx, max_bounces: u32, scan_modes: *mut u32, depth_budget: *mut u32) -> c_int;
+    pub fn rt_build_id() -> *const c_char;
     pub fn rt_timer_start(ctx: *mut rt_ctx) -> c_int;
     pub fn rt_timer_stop(ctx: *mut rt_ctx, milliseconds: *mut f32) -> c_int;
     pub fn rt_camera_new(v_fov_deg: f32, aspect_ratio: f32, aperture: f32, focus_dist: f32,
