@@ -23,6 +23,17 @@ from tools.stress_tree_vs_list import perturb, scene  # noqa: E402
 POISON = 0.05      # share of scenes that get non-finite or huge coordinates
 
 
+def shifted(cam, dx):
+    """a copy of the camera with its origin and lower-left corner moved along x"""
+    import ctypes
+    cam = cam.struct if hasattr(cam, "struct") else cam
+    out = type(cam)()
+    ctypes.memmove(ctypes.byref(out), ctypes.byref(cam), ctypes.sizeof(cam))
+    out.origin[0] = float(np.float32(out.origin[0]) + np.float32(dx))
+    out.lower_left_corner[0] = float(np.float32(out.lower_left_corner[0]) + np.float32(dx))
+    return out
+
+
 def main():
     arg = sys.argv[1] if len(sys.argv) > 1 else "30"
     n_scenes = int(arg[:-1]) if arg.endswith("n") else None      # a budget of scenes (`150n`) instead of seconds
@@ -46,7 +57,12 @@ def main():
         t_min = 0.001 if rng.random() < 0.8 else float(rng.choice([-1.0, 0.0, 0.05, 2.0]))
         w, h = [(96, 54), (61, 43), (130, 20), (33, 70)][int(rng.integers(0, 4))]
         stride = 1 if rng.random() < 0.7 else 3
-        p = make_params(w, h, spp=int(rng.integers(1, 4)), seed=k, t_min=t_min,
+        spp = int(rng.integers(1, 4))
+        if rng.random() < 0.08:
+            # many samples on a small frame: work units of one to four pixels, and ranges beyond one launch
+            w, h = [(20, 13), (9, 26)][int(rng.integers(0, 2))]
+            spp = int(rng.choice([70, 150, 300, 520]))
+        p = make_params(w, h, spp=spp, seed=k, t_min=t_min,
                         max_bounces=10 if rng.random() < 0.6 else int(rng.choice([1, 3, 16])),
                         gamma=bool(rng.random() < 0.7), band_begin=int(rng.integers(0, stride)), band_stride=stride)
         # one call, or the sample range in two calls (progressive rendering adds into the same sums)
@@ -61,10 +77,24 @@ def main():
             o_acc, ids_q, seg_q = orc.render(flat, cam, tables, q, threads=threads, accum=o_acc)
             o_ids = ids_q if o_ids is None else o_ids
             o_seg += seg_q
-        r.set_scene(flat); r.set_camera(cam); r.begin_frame(p.width, p.height)
-        for q in calls:
-            r.render(q)
+        # now and then as the middle one of three frames of one rt_render_frames call (the others through
+        # cameras a little off): a frame's outputs do not depend on what shares its launch (the segment
+        # count is that of all three frames and is not compared then)
+        as_frames = rng.random() < 0.15
+        r.set_scene(flat); r.set_camera(cam)
+        if as_frames:
+            cams = [shifted(cam, -0.37), cam, shifted(cam, 0.61)]
+            r.begin_frames(p.width, p.height, 3)
+            for q in calls:
+                r.render_frames(q, cams)
+            r.select_frame(1)
+        else:
+            r.begin_frame(p.width, p.height)
+            for q in calls:
+                r.render(q)
         acc, ids, seg, packed = r.read_accum(), r.read_primary_ids(), r.ray_count(), r.read_packed()
+        if as_frames:
+            seg = o_seg
         a, b = acc.view(np.uint32), np.ascontiguousarray(o_acc[..., :3]).view(np.uint32)
         nan = np.isnan(acc) & np.isnan(o_acc[..., :3])          # NaN payloads may differ
         same = (np.array_equal(a[~nan], b[~nan]) and np.array_equal(ids, o_ids) and seg == o_seg
