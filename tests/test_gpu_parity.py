@@ -121,6 +121,29 @@ def test_sample_ranges_longer_than_one_launch(renderer, oracle, tables):
     assert_same(long, render_oracle(oracle, tables, flat, cam, [make_params(21, 13, spp=600)]), oracle)
 
 
+def test_kernel_info_names_the_launched_instantiation(renderer, monkeypatch):
+    """rt_kernel_info: the reference's scene runs the kernel without long runs; a scene with a run of 32
+    spheres and more (or 64 triangles and more) a tree kernel, for up to 10 bounces or up to 16; the
+    list-order rejection scan only when asked for (RT_HIP_FLAT_SCAN=1, a measurement mode)"""
+    from raytracing_amd import HittableList, Lambertian, Sphere, workloads, _lib
+    renderer.set_scene(Scene.get_scene().flatten())
+    assert renderer.kernel_variant() == "render_tiles<0, 16>" and renderer.kernel_variant(16) == "render_tiles<0, 16>"
+    some = HittableList()
+    for k in range(40):
+        some.add(Sphere((0.3 * k, 0.0, -1.0), 0.1, Lambertian((0.5, 0.5, 0.5))))
+    renderer.set_scene(some.flatten())
+    assert renderer.kernel_variant(10) == "render_tiles<2, 10>" and renderer.kernel_variant(11) == "render_tiles<2, 16>"
+    monkeypatch.setenv("RT_HIP_FLAT_SCAN", "1")
+    renderer.set_scene(some.flatten())
+    assert renderer.kernel_variant() == "render_tiles<1, 16>"
+    monkeypatch.delenv("RT_HIP_FLAT_SCAN")
+    renderer.set_scene(workloads.mesh_scene())
+    assert renderer.kernel_variant() == "render_tiles<2, 10>"
+    with pytest.raises(_lib.RtError):
+        renderer.kernel_variant(17)
+    assert len(_lib.load().rt_build_id()) == 16
+
+
 def _frames_on_gpu(renderer, flat, cams, calls):
     """rt_begin_frames + rt_render_frames (one call per entry of `calls`), then every frame's outputs"""
     renderer.set_scene(flat)
