@@ -1383,8 +1383,9 @@ void render_tiles(KernArgs by_value) {
                 const uint32_t n_units = (tiles_x * k->n_bands * (FRAMES ? k->n_frames : 1u)) << sub_log2;
                 const uint32_t sample_count = k->p.sample_count;
                 uint32_t u;
-                // (only the kernels with a tree: a scene without one has short launches, and the
-                // three wave-uniform values cost its kernel more than the requests they save)
+                // (only the kernels with a tree, and the one for short units or several frames: a scene
+                // without a tree has short launches, and the three wave-uniform values cost its
+                // kernel more than the requests they save)
                 if (STRETCHES && stretch_next < stretch_end) {
                     u = stretch_next++;
                 } else {
@@ -1773,7 +1774,8 @@ hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_
     if (p.sample_count > DEV_SAMPLE_CHUNK || p.width > 65536u || p.height > 65536u || resident == 0u) return hipErrorInvalidValue;
     const uint64_t max_items = 1ull << DEV_STAGE_ITEM_BITS;    // a unit's colours must fit one ring slot
     // Pixels of a tile per work unit (one pixel, part of a row, or whole rows): as many as a ring slot's
-    // 512 work items (eight per lane) allow with the samples of this launch, 64 at most.  Measured on 4K frames at 64 samples per launch, whole
+    // 512 work items (eight per lane) allow with the samples of this launch, 64 at most.  Fewer items per
+    // unit are worse: measured on 4K frames at 64 samples per launch, whole
     // frame / one eighth of the bands, 10,000 spheres: 4 pixels 135.2 / 17.4 ms, 8 pixels 132.2 /
     // 17.8, 16 pixels 132.1 / 19.1, 32 pixels 135.3 / 21.9, 64 pixels 139.1 / 26.5; the
     // million-triangle scene 69.8 / 9.2 ms with 4, 64.9 / 9.4 with 8, 75.9 / 22.1 with 64.
@@ -1804,7 +1806,7 @@ hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_
     // end (the default scene at 1080p, 32 units per wave: 8.0 ms with stretches of up to 8 from the
     // start, 4.5 without; a wave's stretch on the way was asked for a stretch earlier), so they are
     // used only while much is left, and only by the kernels with a tree: 10,000 spheres 4K -0.4 %, a
-    // million triangles -1 %.
+    // million triangles -1 %.  (The kernel for short units or several frames asks for one batch at a time.)
     // Short units (a launch of less than eight samples: whole tiles with fewer than 512 items) come in
     // batches that make up for it, as far as every wave still gets a batch
     const uint64_t unit_items = (uint64_t)p.sample_count << unit_px_log2;
@@ -1818,7 +1820,7 @@ hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_
     rtk::KernArgs ka{sc, cam, p, fr, n_bands, r, (uint32_t)stretch_unit, fetch_min, cams, n_frames, (uint32_t)unit_batch};
     if (p.max_bounces > RT_MAX_BOUNCES) return hipErrorInvalidValue;
     const uint32_t which = frames ? 8u : kernel_index(sc.modes, p.max_bounces);
-    if (which >= 4u) {
+    if (which >= 4u && which < 8u) {
         // the deep material stack leaves less room for the tree's top levels
         ka.dsc.lds_level = sc.lds_deep_level; ka.dsc.lds_first = sc.lds_deep_first; ka.dsc.lds_count = sc.lds_deep_count;
         if (sc.lds_deep_level == 0xffffffffu) ka.dsc.lds_run = 0xffffffffu;
