@@ -216,6 +216,18 @@ def test_frames_in_one_launch_equal_frames_one_by_one(renderer, oracle, tables):
         renderer.render_frames(p, cams)            # more cameras than frames
     with pytest.raises(_lib.RtError):
         renderer.select_frame(3)
+    # fewer cameras than frames: the first two frames are rendered again (added to), the third is not
+    renderer.select_frame(2)
+    third = renderer.read_sample_counts()
+    renderer.render_frames(p, cams[:2])
+    renderer.select_frame(0)
+    assert int(renderer.read_sample_counts().max()) == 4
+    renderer.select_frame(2)
+    assert np.array_equal(renderer.read_sample_counts(), third)
+    for w_, h_, n_ in ((8, 8, 0), (8, 8, 4097), (65536, 65536, 1), (40000, 40000, 3)):
+        with pytest.raises(_lib.RtError) as e:
+            renderer.begin_frames(w_, h_, n_)
+        assert e.value.code == _lib.RT_E_BADARG
     renderer.begin_frame(8, 8)                     # back to one frame for the tests that follow
 
 
