@@ -2,7 +2,7 @@
 # Runs the GPU steps given on stdin (one shell command per line, '#' comments allowed) one after the
 # other, each under its own time limit (first word of the line, seconds), output appended to
 # gpurun_out/<tag>.log; stops at the first step that fails or times out.
-# usage: tools/run_steps.sh <tag> < steps.txt
+# usage: tools/run_steps.sh <tag> < tools/steps/verify.txt   (through gpurun: the steps file must be in the tree)
 TAG=${1:?tag}
 LOG=gpurun_out/$TAG.log
 mkdir -p gpurun_out
