@@ -280,3 +280,30 @@ def test_mesh_workload_comes_through_the_obj_reader(tmp_path):
     assert workloads.write_mesh_obj(str(again)) == (482, 960)
     with open(workloads.MESH_OBJ, "rb") as f, open(again, "rb") as g:
         assert f.read() == g.read()
+
+
+def test_bench_joins_counter_passes_only_with_their_own_build(monkeypatch):
+    """bench.py takes the per-segment instruction counts of its roofline from the committed counter
+    passes under profiles/, and only when they were taken on the library it is running (rt_build_id):
+    with the library of the tree every configuration has its record; with any other build id the
+    fraction comes back empty together with the reason, not with the old kernel's numbers"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for key in ("c1", "c2", "c3", "c4", "c5"):
+        rec, why = bench.counters_from_profile(key)
+        assert rec is not None and why is None, (key, why)
+        assert rec["library_build"] == bench.library_build_id()
+        assert bench.hbm_traffic_from_profile(key, rec["spp_per_launch"]) > 0
+    flat = Scene.get_scene().flatten()
+    roof = bench.valu_roofline("c2", "render_tiles<0, 16>", 2.9e8, 4.4, 64, 220, flat)
+    assert 0.2 < roof["frac"] < 0.6 and roof["hbm_gbps"] > 0 and "frac_null_because" not in roof
+    monkeypatch.setattr(bench, "library_build_id", lambda: "0123456789abcdef")
+    rec, why = bench.counters_from_profile("c4")
+    assert rec is None and "0123456789abcdef" in why
+    roof = bench.valu_roofline("c4", "render_tiles<2, 10>", 6.4e9, 390.0, 256, 180094, flat)
+    assert roof["frac"] is None and roof["traffic"] is None and "library build" in roof["frac_null_because"]
+    cores, allowed, quota = bench.host_cores()
+    assert 1 <= cores <= min(allowed, 256) and (quota is None or cores <= quota)
