@@ -43,6 +43,8 @@ struct Ctx {
     int32_t *d_ids = nullptr;
     rt_camera *d_cams = nullptr;      // the cameras of the last rt_render_frames, n_frames of them
     std::vector<rt_camera> cams_host; // what d_cams holds
+    hipEvent_t ev_cams = nullptr;     // the upload of cams_host has read it
+    bool cams_in_flight = false;
     // the selected frame's part of the three buffers
     size_t frame_px() const { return (size_t)W * H; }
     float4 *accum() const { return d_accum + frame_px() * sel; }
@@ -92,7 +94,9 @@ void free_frame(Ctx *c) {
     if (c->d_packed) (void)hipFree(c->d_packed);
     if (c->d_ids) (void)hipFree(c->d_ids);
     if (c->d_cams) (void)hipFree(c->d_cams);
-    c->d_cams = nullptr; c->n_frames = 0; c->sel = 0; c->cams_host.clear();
+    c->d_cams = nullptr; c->n_frames = 0; c->sel = 0;
+    // (callers have synchronised the stream: no upload still reads the copy)
+    c->cams_host.clear(); c->cams_in_flight = false;
     if (c->d_block) (void)hipFree(c->d_block);
     if (c->d_gather) (void)hipFree(c->d_gather);
     c->d_block = nullptr; c->d_gather = nullptr; c->block_px = c->gather_px = 0;
@@ -145,6 +149,7 @@ int rt_create(int device, rt_ctx **out) {
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreateWithFlags(&c->ev_block, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&c->ev_cams, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipMalloc(reinterpret_cast<void **>(&c->d_disc), 128 * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc(reinterpret_cast<void **>(&c->d_sphere), 768 * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc(reinterpret_cast<void **>(&c->d_screen), 16384 * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc");
@@ -178,6 +183,7 @@ void rt_destroy(rt_ctx *ctx) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_block) (void)hipEventDestroy(c->ev_block);
+    if (c->ev_cams) (void)hipEventDestroy(c->ev_cams);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -391,12 +397,18 @@ int rt_render_frames(rt_ctx *ctx, const rt_params *p, const rt_camera *cameras, 
     HIP_TRY(c, hipSetDevice(c->device));
     if ((rc = ensure_stage(c)) != RT_OK) return rc;
     if (rtk_has_frames_kernel(c->dsc.modes)) {
-        // one launch (per 512 samples) over the tiles of all frames; the cameras go to device memory first
-        // (the copy from the caller's pageable memory has left it when the call returns)
-        // (not when they are the cameras that are there already: progressive calls on the same frames)
+        // one launch (per 512 samples) over the tiles of all frames; the cameras go to device memory first,
+        // through a copy of the context's own (the caller's may go away after the call), on the stream, behind
+        // the launches that still read the last ones.  Not when they are the cameras that are there already:
+        // progressive calls on the same frames.
         if (c->cams_host.size() != n_frames || std::memcmp(c->cams_host.data(), cameras, n_frames * sizeof(rt_camera)) != 0) {
+            // (the last upload must have read the context's copy before it is overwritten)
+            if (c->cams_in_flight) HIP_TRY(c, hipEventSynchronize(c->ev_cams));
+            c->cams_in_flight = false;
             c->cams_host.assign(cameras, cameras + n_frames);
             HIP_TRY(c, hipMemcpyAsync(c->d_cams, c->cams_host.data(), n_frames * sizeof(rt_camera), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipEventRecord(c->ev_cams, c->stream));
+            c->cams_in_flight = true;
         }
         DevFrame fr{c->d_disc, c->d_sphere, c->d_screen, c->d_accum, c->d_ids, c->d_stage, c->d_segments,
                     nullptr, nullptr, 0u};
