@@ -396,7 +396,7 @@ int rt_render_frames(rt_ctx *ctx, const rt_params *p, const rt_camera *cameras, 
         return fail(c, RT_E_BADARG, "rt_render_frames: width/height differ from rt_begin_frames");
     HIP_TRY(c, hipSetDevice(c->device));
     if ((rc = ensure_stage(c)) != RT_OK) return rc;
-    if (rtk_has_frames_kernel(c->dsc.modes)) {
+    if (rtk_has_frames_kernel(c->dsc.modes) && n_frames > 1u) {
         // one launch (per 512 samples) over the tiles of all frames; the cameras go to device memory first,
         // through a copy of the context's own (the caller's may go away after the call), on the stream, behind
         // the launches that still read the last ones.  Not when they are the cameras that are there already:
@@ -414,8 +414,8 @@ int rt_render_frames(rt_ctx *ctx, const rt_params *p, const rt_camera *cameras, 
                     nullptr, nullptr, 0u};
         return enqueue_render(c, p, fr, c->stage_waves, c->d_queue, nullptr, 0, c->d_cams, n_frames);
     }
-    // scenes with long runs: their kernels take one frame per launch, and a frame of such a scene keeps a
-    // launch busy by itself
+    // a single frame, or a scene with long runs: the kernels for those take one frame per launch, and a
+    // frame of such a scene keeps a launch busy by itself
     const rt_camera keep = c->cam;
     const uint32_t keep_sel = c->sel;
     for (uint32_t f = 0; f < n_frames && rc == RT_OK; ++f) {

@@ -158,14 +158,15 @@ def _frames_on_gpu(renderer, flat, cams, calls):
     return out, renderer.ray_count()
 
 
-@pytest.mark.parametrize("w,h,spp,n_frames", [(600, 337, 1, 10), (61, 43, 3, 4), (120, 67, 70, 2)])
+@pytest.mark.parametrize("w,h,spp,n_frames", [(600, 337, 1, 10), (61, 43, 3, 4), (120, 67, 70, 2), (40, 24, 2, 1)])
 def test_several_frames_in_one_launch(renderer, oracle, tables, w, h, spp, n_frames):
     """rt_render_frames: the reference's run of ten frames (src/raytracer.rs:32,165; the camera one dolly
     step further per frame, src/scene/mod.rs:78-83) in ONE launch at its own size and sample count, and
     smaller cases with partial tiles and units of a few pixels: every frame's sums, ids, packed pixels
     and sample counts are the oracle's for that frame's camera, the segment count is the total"""
     flat = Scene.get_scene().flatten()
-    cams = [oracle.scene_camera(f, 0.1 if spp > 1 else 0.0) for f in range(n_frames)]
+    cams = [oracle.scene_camera(f + 5, 0.1 if spp > 1 else 0.0) for f in range(n_frames)]
+    renderer.set_camera(oracle.scene_camera(0, 0.0))     # not the camera of any frame: the call must not use it
     p = make_params(w, h, spp=spp)
     got, seg = _frames_on_gpu(renderer, flat, cams, [p])
     total = 0
