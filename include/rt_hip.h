@@ -256,7 +256,8 @@ int rt_check_arith(rt_ctx *ctx, uint64_t operands, uint32_t seed, uint64_t misma
  * scan_modes bit 0 = some sphere run goes through the list-order rejection scan, bit 1 = some
  * run is walked through a box tree; depth_budget = the largest max_bounces that kernel takes. */
 int rt_kernel_info(rt_ctx *ctx, uint32_t max_bounces, uint32_t *scan_modes, uint32_t *depth_budget);
-/* First 16 hex digits of the SHA-256 of the kernel sources the library was built from. */
+/* First 16 hex digits of the SHA-256 of the sources the library was built from that decide what a
+ * launch executes (kernels, scene layout and tree builder, launch code). */
 const char *rt_build_id(void);
 /* HIP-event stopwatch on the context's stream; stop synchronises */
 int rt_timer_start(rt_ctx *ctx);

@@ -230,7 +230,7 @@ __host__ __device__ constexpr int occ_hint_of(int modes) { return modes == 0 ? R
 // (64-sample launches of the whole frame, 1 / 16 / 24 / 32 lanes: default scene 1080p 4.97 / 4.70 / 4.57 /
 // 4.58 ms; with a tree 8 / 16 / 20 / 24 / 32 lanes: 10,000 spheres 4K 107.8 / 105.6 / 105.6 / 106.4 /
 // 107.6 ms, a million triangles 53.9 / 51.4 / 50.5 / 50.3 / 50.3, 960-triangle mesh 10.35 / 10.08 / 9.97 /
-// 9.94 / 9.97; with the final kernel of round 2, 20 / 24 lanes: 10,000 spheres 98.9 / 99.1 ms, a million
+// 9.94 / 9.97; with the later kernel whose nodes store their planes twice, 20 / 24 lanes: 10,000 spheres 98.9 / 99.1 ms, a million
 // triangles 46.8 / 46.2, mesh 9.27 / 9.20: a scene whose largest tree holds triangles waits for 24)
 #ifndef RTK_FETCH_MIN0
 #define RTK_FETCH_MIN0 24

@@ -249,14 +249,14 @@ def test_oracle_rejects_malformed_scenes(oracle, tables):
 
 
 def test_library_build_id_matches_the_kernel_sources():
-    """rt_build_id() is the SHA-256 (first 16 hex digits) of the kernel sources the library in the tree
-    was built from; bench.py uses it to tell whether committed counter passes belong to this build.  A
+    """rt_build_id() is the SHA-256 (first 16 hex digits) of the sources that decide what a launch executes
+    (kernels, scene layout and tree builder, launch code) as the library in the tree was built from them; bench.py uses it to tell whether committed counter passes belong to this build.  A
     library that is older than the sources next to it fails here."""
     import hashlib
     from raytracing_amd import _lib
     csrc = os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), "csrc")
     h = hashlib.sha256()
-    for name in ("rt_kernels.hip", "rt_device.h"):
+    for name in ("rt_kernels.hip", "rt_device.h", "rt_scene_build.cpp", "rt_scene_build.h", "rt_api.cpp"):
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
     assert _lib.load().rt_build_id().decode() == h.hexdigest()[:16]
