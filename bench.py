@@ -180,6 +180,10 @@ def valu_roofline(key, kernel, segments_per_launch, kernel_ms, spp_per_launch, f
     prof, why_not = counters_from_profile(key)
     seg_per_s = segments_per_launch / (kernel_ms * 1e-3)
     traffic = hbm_traffic_from_profile(key, spp_per_launch)
+    if traffic is not None and prof is not None and prof.get("segments_per_launch"):
+        # the counter pass rendered the whole frame in one launch; a rank of a multi-GPU run renders its
+        # share of the bands, and the traffic (nearly all of it per-sample staging) goes with the segments
+        traffic = int(traffic * segments_per_launch / prof["segments_per_launch"])
     out = {"bound": "valu", "achieved": None, "peak": PEAK_VALU_LANE_TOPS, "unit": "TFLOP/s", "frac": None,
            "traffic": traffic,
            # the HBM side of the same launch: bytes moved / kernel time against the 8 TB/s peak
