@@ -28,6 +28,11 @@ x the segments of this run / the kernel time of this run (HIP events).  `peak` i
 which the chip issues them, 256 CUs x 4 SIMDs x 32 lanes per clock x 2.4 GHz = 78.6 T/s (the
 157.3 TFLOP/s FP32 vector peak counts a fused multiply-add as two).  The work of the reference's
 linear scan that the box tree skips is reported separately (`algorithmic_equivalent`).
+The counter passes are used only if they were taken on the library build that is running
+(`library_build`, rt_build_id); otherwise `frac` is null and `frac_null_because` says why.
+`traffic`, `hbm_gbps`, `hbm_frac_of_8TBps`: HBM bytes of the launch from the same passes, and their
+rate over this run's kernel time against 8 TB/s.  `config.others` holds the same figures for the
+other configurations, measured briefly on a single GPU.
 
 Rehearsal of the multi-rank path on a box with one GPU (not a measurement):
 RT_BENCH_REHEARSAL=1 puts every rank on device 0, gathers through gloo and host
