@@ -1782,6 +1782,11 @@ hipError_t rtk_launch_render(const DevScene &sc, const rt_camera &cam, const rt_
     if (unit_px_log2 < 0 || unit_px_log2 > 6) {
         unit_px_log2 = 6;
         while (unit_px_log2 > 0 && ((uint64_t)p.sample_count << unit_px_log2) > max_items) --unit_px_log2;
+        // With a tree and many samples, half of that: the rays of a wave then come from fewer pixels and walk
+        // more alike, which is worth more than the longer unit (whole 4K frame, 256 samples per launch, units
+        // of one / two pixels: 10,000 spheres 387.0 / 390.4 ms, a million triangles 177.1 / 177.7, mesh scene
+        // at 1080p 36.03 / 36.05; 128 samples, two / four pixels: 196.5 / 197.1, 90.4 / 90.7, 18.33 / 18.24)
+        if ((sc.modes & 2u) && unit_px_log2 > 0 && p.sample_count >= 128u) --unit_px_log2;
         // a small launch (one GPU's share of a frame): half as long units, so that a wave still
         // gets a few dozen of them.  Scenes without a tree have short segments and feel the cost of
         // a unit more (default scene at 64 samples, 256- against 512-item units: whole 1080p frame
