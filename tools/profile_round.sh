@@ -1,18 +1,19 @@
 #!/bin/bash
 # Collects what is committed under profiles/ in one GPU session:
-#   - kernel trace + stats of the default bench.py run (the line the driver records),
 #   - per workload (default: all five) four counter passes of a short bench.py run: two SQ passes
-#     (issue and lane counters; instruction types), HBM reads, HBM writes.
-# Outputs land in gpurun_out/prof/<workload>/; copy into profiles/ with tools/collect_counters.py.
-# usage: tools/profile_round.sh <tag> [workloads...]      (e.g. r02 c4 c2)
+#     (issue and lane counters; instruction types), HBM reads, HBM writes; tools/collect_counters.py turns
+#     them into profiles/sq_counters.json and profiles/hbm_traffic.json (copied to gpurun_out/prof/ as well),
+#   - then kernel trace + stats of the default bench.py run (the line the driver records), which joins its
+#     timings with the counter records just taken.
+# Outputs land in gpurun_out/prof/; copy the two .json files, <tag>_bench_default* and <workload>/pmc_*.csv
+# (as <tag>_<workload>_pmc_*.csv) into profiles/.
+# usage: tools/profile_round.sh <tag> [workloads...]      (e.g. r03 c4 c2)
 set -u
-TAG=${1:-r02}; shift
+TAG=${1:-r03}; shift
 WLS=${*:-c1 c2 c3 c4 c5}
 OUT=gpurun_out/prof
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout -s KILL 400 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python3 bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/trace.err || exit 1
-cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_default_kernel_stats.csv
 for W in $WLS; do
   D=$OUT/$W; mkdir -p $D
   # (a step is the whole frame, up to 512 samples per launch: c5 takes two launches per step, one step is enough)
@@ -27,7 +28,11 @@ for W in $WLS; do
   cp $(find $D/fetch -name "*counter_collection.csv" | head -1) $D/pmc_fetch_size.csv
   cp $(find $D/write -name "*counter_collection.csv" | head -1) $D/pmc_write_size.csv
   rm -rf $D/sq_a $D/sq_b $D/fetch $D/write
+  python3 tools/collect_counters.py $W $D $TAG > $D/collected.json || exit 1
   echo "$W: counter passes done"
 done
+cp profiles/sq_counters.json profiles/hbm_traffic.json $OUT/
+timeout -s KILL 400 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python3 bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/trace.err || exit 1
+cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_default_kernel_stats.csv
 tail -1 $OUT/${TAG}_bench_default.json | cut -c1-300
 cat $OUT/${TAG}_bench_default_kernel_stats.csv
